@@ -1,0 +1,480 @@
+/*
+ * aad_hip_engine.hip - host side of the batched C-ABI declared in include/aad_hip.h:
+ * contexts, plans (uploaded stream tables), kernel launches and the host-memory convenience
+ * calls.  Device code lives in aad_device.hip.h.  gfx950 only; there is no CPU code path -
+ * every entry point that needs the GPU fails with AAD_APIRESULT_NG when HIP does.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/aad_hip.h"
+#include "aad_device.hip.h"
+#include "aad_format.h"
+#include "aad_hip_internal.h"
+
+static_assert(sizeof(AADHipStreamDesc) == sizeof(aad::StreamDesc), "stream table layout");
+static_assert(sizeof(AADHipLaneState) == sizeof(aad::LaneStateRecord), "lane state layout");
+
+struct AADHipContext {
+  int device;
+  hipStream_t stream;
+  bool owns_stream;
+  char last_error[256];
+};
+
+struct AADHipEncodePlan {
+  AADHipContext *ctx;
+  aad::EncodeArgs args;
+  aad::StreamDesc *d_streams;
+};
+
+struct AADHipDecodePlan {
+  AADHipContext *ctx;
+  aad::DecodeArgs args;
+  aad::StreamDesc *d_streams;
+  uint64_t *d_prefix;
+};
+
+namespace {
+
+constexpr unsigned kWorkgroup = 64; /* one wave per workgroup: lanes are scarce in every BASELINE
+                                       config, so spread waves over as many SIMDs as possible */
+
+bool hip_ok(AADHipContext *ctx, hipError_t e, const char *what)
+{
+  if (e == hipSuccess) return true;
+  if (ctx) snprintf(ctx->last_error, sizeof(ctx->last_error), "%s: %s", what, hipGetErrorString(e));
+  return false;
+}
+
+struct DeviceGuard { /* select the context's device for the calling thread, restore on exit */
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(AADHipContext *ctx)
+  {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+  }
+  ~DeviceGuard()
+  {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+template <typename T>
+bool upload(AADHipContext *ctx, T **dst, const T *src, size_t count)
+{
+  if (!hip_ok(ctx, hipMalloc((void **)dst, sizeof(T) * (count ? count : 1)), "hipMalloc")) return false;
+  if (count == 0) return true;
+  /* pageable source: the copy is complete (staged) when this returns */
+  return hip_ok(ctx, hipMemcpyAsync(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync") &&
+         hip_ok(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+} /* namespace */
+
+extern "C" {
+
+int32_t AADHip_GetDeviceCount(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+AADApiResult AADHip_ContextCreate(int32_t device_index, void *hip_stream, struct AADHipContext **context)
+{
+  if (context == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
+  *context = nullptr;
+  if (device_index < 0 || device_index >= AADHip_GetDeviceCount()) return AAD_APIRESULT_NG;
+  AADHipContext *ctx = new (std::nothrow) AADHipContext();
+  if (ctx == nullptr) return AAD_APIRESULT_NG;
+  ctx->device = device_index;
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  ctx->owns_stream = false;
+  ctx->last_error[0] = 0;
+  DeviceGuard guard(ctx);
+  if (!guard.ok) {
+    delete ctx;
+    return AAD_APIRESULT_NG;
+  }
+  if (hip_stream == nullptr) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return AAD_APIRESULT_NG;
+    }
+    ctx->owns_stream = true;
+  }
+  *context = ctx;
+  return AAD_APIRESULT_OK;
+}
+
+void AADHip_ContextDestroy(struct AADHipContext *ctx)
+{
+  if (ctx == nullptr) return;
+  {
+    DeviceGuard guard(ctx);
+    if (guard.ok) {
+      (void)hipStreamSynchronize(ctx->stream);
+      if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    }
+  }
+  delete ctx;
+}
+
+AADApiResult AADHip_ContextSynchronize(struct AADHipContext *ctx)
+{
+  if (ctx == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
+  DeviceGuard guard(ctx);
+  if (!guard.ok) return AAD_APIRESULT_NG;
+  return hip_ok(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+}
+
+const char *AADHip_ContextLastError(const struct AADHipContext *ctx) { return ctx ? ctx->last_error : ""; }
+
+uint64_t AADHip_CalculateEncodedSize(const struct AADEncodeParameter *parameter, uint32_t num_samples)
+{
+  AADHeaderInfo h;
+  if (num_samples == 0) return 0;
+  if (AADFormat_ParameterToHeader(parameter, num_samples, AAD_HIP_MAX_NUM_CHANNELS, &h) != AAD_APIRESULT_OK) return 0;
+  if (!AADFormat_HeaderFieldsValid(&h, AAD_HIP_MAX_NUM_CHANNELS)) return 0;
+  return AADFormat_EncodedSize(&h);
+}
+
+/* ------------------------------------------------------------------------------- encode -- */
+
+AADApiResult AADHip_EncodePlanCreate(struct AADHipContext *ctx, const struct AADEncodeParameter *parameter,
+                                     uint32_t num_streams, const struct AADHipStreamDesc *streams,
+                                     struct AADHipEncodePlan **plan)
+{
+  if (ctx == nullptr || parameter == nullptr || plan == nullptr || (num_streams != 0 && streams == nullptr))
+    return AAD_APIRESULT_INVALID_ARGUMENT;
+  *plan = nullptr;
+  AADHeaderInfo h;
+  if (AADFormat_ParameterToHeader(parameter, 1, AAD_HIP_MAX_NUM_CHANNELS, &h) != AAD_APIRESULT_OK)
+    return AAD_APIRESULT_INVALID_FORMAT;
+  /* what AADEncoder_EncodeHeader would reject (bits == 1, zero rate, M/S on mono, ...) */
+  if (!AADFormat_HeaderFieldsValid(&h, AAD_HIP_MAX_NUM_CHANNELS)) return AAD_APIRESULT_INVALID_FORMAT;
+  if (h.ch_process_method == AAD_CH_PROCESS_METHOD_MS && h.num_channels != 2) return AAD_APIRESULT_INVALID_FORMAT;
+  for (uint32_t i = 0; i < num_streams; i++) {
+    if (streams[i].num_samples == 0) return AAD_APIRESULT_INVALID_FORMAT; /* src/aad_encoder.c:157-159 */
+    h.num_samples = streams[i].num_samples;
+    if (streams[i].data_size < AADFormat_EncodedSize(&h)) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
+  }
+
+  AADHipEncodePlan *p = new (std::nothrow) AADHipEncodePlan();
+  if (p == nullptr) return AAD_APIRESULT_NG;
+  p->ctx = ctx;
+  p->d_streams = nullptr;
+  DeviceGuard guard(ctx);
+  if (!guard.ok || !upload(ctx, &p->d_streams, reinterpret_cast<const aad::StreamDesc *>(streams), num_streams)) {
+    if (p->d_streams) (void)hipFree(p->d_streams);
+    delete p;
+    return AAD_APIRESULT_NG;
+  }
+  memset(&p->args, 0, sizeof(p->args));
+  p->args.streams = p->d_streams;
+  p->args.num_streams = num_streams;
+  p->args.channels = h.num_channels;
+  p->args.block_size = h.block_size;
+  p->args.samples_per_block = h.num_samples_per_block;
+  p->args.mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
+  p->args.trials = parameter->num_encode_trials;
+  h.num_samples = 0;
+  AADFormat_PutHeader(&h, p->args.header_template);
+  p->args.bits = h.bits_per_sample;
+  *plan = p;
+  return AAD_APIRESULT_OK;
+}
+
+void AADHip_EncodePlanDestroy(struct AADHipEncodePlan *plan)
+{
+  if (plan == nullptr) return;
+  DeviceGuard guard(plan->ctx);
+  if (guard.ok) {
+    (void)hipStreamSynchronize(plan->ctx->stream);
+    (void)hipFree(plan->d_streams);
+  }
+  delete plan;
+}
+
+AADApiResult AADHip_EncodePlanRun(struct AADHipEncodePlan *plan, const int16_t *device_pcm, uint8_t *device_data,
+                                  struct AADHipLaneState *device_state)
+{
+  if (plan == nullptr || device_pcm == nullptr || device_data == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
+  AADHipContext *ctx = plan->ctx;
+  if (plan->args.num_streams == 0) return AAD_APIRESULT_OK;
+  DeviceGuard guard(ctx);
+  if (!guard.ok) return AAD_APIRESULT_NG;
+  aad::EncodeArgs a = plan->args;
+  a.pcm = device_pcm;
+  a.data = device_data;
+  a.state = reinterpret_cast<aad::LaneStateRecord *>(device_state);
+  const uint64_t lanes = (uint64_t)a.num_streams * a.channels;
+  const dim3 grid((unsigned)((lanes + kWorkgroup - 1) / kWorkgroup)), block(kWorkgroup);
+  switch (a.bits) {
+    case 4: hipLaunchKernelGGL(aad::encode_streams_kernel<4>, grid, block, 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL(aad::encode_streams_kernel<3>, grid, block, 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL(aad::encode_streams_kernel<2>, grid, block, 0, ctx->stream, a); break;
+    default: return AAD_APIRESULT_INVALID_FORMAT;
+  }
+  return hip_ok(ctx, hipGetLastError(), "encode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+}
+
+/* ------------------------------------------------------------------------------- decode -- */
+
+AADApiResult AADHip_DecodePlanCreate(struct AADHipContext *ctx, const struct AADHeaderInfo *format,
+                                     int32_t has_file_header, uint32_t num_streams,
+                                     const struct AADHipStreamDesc *streams, struct AADHipDecodePlan **plan)
+{
+  if (ctx == nullptr || format == nullptr || plan == nullptr || (num_streams != 0 && streams == nullptr))
+    return AAD_APIRESULT_INVALID_ARGUMENT;
+  *plan = nullptr;
+  AADHeaderInfo h = *format;
+  h.num_samples = 1; /* per-stream counts come from the table */
+  if (!AADFormat_HeaderAcceptedByDecoder(&h, AAD_HIP_MAX_NUM_CHANNELS)) return AAD_APIRESULT_INVALID_FORMAT;
+  if (h.ch_process_method == AAD_CH_PROCESS_METHOD_MS && h.num_channels != 2) return AAD_APIRESULT_INVALID_FORMAT;
+
+  std::vector<uint64_t> prefix((size_t)num_streams + 1);
+  uint64_t blocks = 0;
+  const uint32_t head = has_file_header ? AAD_HEADER_SIZE : 0;
+  for (uint32_t i = 0; i < num_streams; i++) {
+    prefix[i] = blocks;
+    /* the reference walks blocks while samples remain AND bytes remain (src/aad_decoder.c:514) */
+    const uint64_t by_samples = ((uint64_t)streams[i].num_samples + h.num_samples_per_block - 1) / h.num_samples_per_block;
+    const uint64_t payload = streams[i].data_size > head ? streams[i].data_size - head : 0;
+    const uint64_t by_bytes = (payload + h.block_size - 1) / h.block_size;
+    const uint64_t nblk = by_samples < by_bytes ? by_samples : by_bytes;
+    /* a present block shorter than its header is the reference's INSUFFICIENT_DATA (src/aad_decoder.c:347-349) */
+    if (nblk > 0) {
+      const uint64_t last_bytes = payload - (nblk - 1) * h.block_size;
+      if (last_bytes < (uint64_t)AAD_BLOCK_HEADER_BYTES_PER_CH * h.num_channels) return AAD_APIRESULT_INSUFFICIENT_DATA;
+    }
+    blocks += nblk;
+  }
+  prefix[num_streams] = blocks;
+
+  AADHipDecodePlan *p = new (std::nothrow) AADHipDecodePlan();
+  if (p == nullptr) return AAD_APIRESULT_NG;
+  p->ctx = ctx;
+  p->d_streams = nullptr;
+  p->d_prefix = nullptr;
+  DeviceGuard guard(ctx);
+  if (!guard.ok || !upload(ctx, &p->d_streams, reinterpret_cast<const aad::StreamDesc *>(streams), num_streams) ||
+      !upload(ctx, &p->d_prefix, prefix.data(), prefix.size())) {
+    if (p->d_streams) (void)hipFree(p->d_streams);
+    if (p->d_prefix) (void)hipFree(p->d_prefix);
+    delete p;
+    return AAD_APIRESULT_NG;
+  }
+  memset(&p->args, 0, sizeof(p->args));
+  p->args.streams = p->d_streams;
+  p->args.block_prefix = p->d_prefix;
+  p->args.total_blocks = blocks;
+  p->args.num_streams = num_streams;
+  p->args.channels = h.num_channels;
+  p->args.block_size = h.block_size;
+  p->args.samples_per_block = h.num_samples_per_block;
+  p->args.header_bytes = head;
+  p->args.mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
+  p->args.bits = h.bits_per_sample;
+  *plan = p;
+  return AAD_APIRESULT_OK;
+}
+
+void AADHip_DecodePlanDestroy(struct AADHipDecodePlan *plan)
+{
+  if (plan == nullptr) return;
+  DeviceGuard guard(plan->ctx);
+  if (guard.ok) {
+    (void)hipStreamSynchronize(plan->ctx->stream);
+    (void)hipFree(plan->d_streams);
+    (void)hipFree(plan->d_prefix);
+  }
+  delete plan;
+}
+
+AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *device_data, int16_t *device_pcm)
+{
+  if (plan == nullptr || device_data == nullptr || device_pcm == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
+  AADHipContext *ctx = plan->ctx;
+  if (plan->args.total_blocks == 0) return AAD_APIRESULT_OK;
+  DeviceGuard guard(ctx);
+  if (!guard.ok) return AAD_APIRESULT_NG;
+  aad::DecodeArgs a = plan->args;
+  a.data = device_data;
+  a.pcm = device_pcm;
+  const uint64_t lanes = a.total_blocks * a.channels;
+  const dim3 grid((unsigned)((lanes + kWorkgroup - 1) / kWorkgroup)), block(kWorkgroup);
+  switch (a.bits) {
+    case 4: hipLaunchKernelGGL(aad::decode_blocks_kernel<4>, grid, block, 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL(aad::decode_blocks_kernel<3>, grid, block, 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL(aad::decode_blocks_kernel<2>, grid, block, 0, ctx->stream, a); break;
+    default: return AAD_APIRESULT_INVALID_FORMAT;
+  }
+  return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+}
+
+/* --------------------------------------------------------------- host-memory convenience -- */
+
+namespace {
+struct DeviceBuffer {
+  void *p = nullptr;
+  ~DeviceBuffer()
+  {
+    if (p) (void)hipFree(p);
+  }
+};
+uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+} /* namespace */
+
+AADApiResult AADHip_EncodeBatch(struct AADHipContext *ctx, const struct AADEncodeParameter *parameter,
+                                uint32_t num_streams, const int16_t *const *pcm, const uint32_t *num_samples,
+                                uint8_t *const *data, const uint64_t *data_capacity, uint64_t *output_size,
+                                struct AADHipLaneState *state)
+{
+  if (ctx == nullptr || parameter == nullptr || (num_streams != 0 && (pcm == nullptr || num_samples == nullptr ||
+      data == nullptr || data_capacity == nullptr)))
+    return AAD_APIRESULT_INVALID_ARGUMENT;
+  if (num_streams == 0) return AAD_APIRESULT_OK;
+  std::vector<AADHipStreamDesc> table(num_streams);
+  std::vector<uint64_t> sizes(num_streams);
+  uint64_t pcm_elems = 0, data_bytes = 0;
+  const uint32_t ch = parameter->num_channels;
+  for (uint32_t i = 0; i < num_streams; i++) {
+    if (pcm[i] == nullptr || data[i] == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
+    sizes[i] = AADHip_CalculateEncodedSize(parameter, num_samples[i]);
+    if (sizes[i] == 0) return AAD_APIRESULT_INVALID_FORMAT;
+    if (data_capacity[i] < sizes[i]) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
+    table[i].pcm_offset = pcm_elems;
+    table[i].data_offset = data_bytes;
+    table[i].data_size = sizes[i];
+    table[i].num_samples = num_samples[i];
+    table[i].reserved = 0;
+    pcm_elems += round_up((uint64_t)num_samples[i] * ch, 8);
+    data_bytes += round_up(sizes[i], 16);
+  }
+  AADHipEncodePlan *plan = nullptr;
+  AADApiResult rc = AADHip_EncodePlanCreate(ctx, parameter, num_streams, table.data(), &plan);
+  if (rc != AAD_APIRESULT_OK) return rc;
+  DeviceGuard guard(ctx);
+  DeviceBuffer d_pcm, d_data, d_state;
+  const size_t state_bytes = sizeof(AADHipLaneState) * (size_t)num_streams * ch;
+  rc = AAD_APIRESULT_NG;
+  do {
+    if (!guard.ok) break;
+    if (!hip_ok(ctx, hipMalloc(&d_pcm.p, pcm_elems * sizeof(int16_t) + 64), "hipMalloc pcm")) break;
+    if (!hip_ok(ctx, hipMalloc(&d_data.p, data_bytes + 64), "hipMalloc data")) break;
+    if (state) {
+      if (!hip_ok(ctx, hipMalloc(&d_state.p, state_bytes), "hipMalloc state")) break;
+      if (!hip_ok(ctx, hipMemcpyAsync(d_state.p, state, state_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D state")) break;
+    }
+    bool ok = true;
+    for (uint32_t i = 0; i < num_streams && ok; i++)
+      ok = hip_ok(ctx, hipMemcpyAsync((int16_t *)d_pcm.p + table[i].pcm_offset, pcm[i],
+                                      (size_t)num_samples[i] * ch * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream), "H2D pcm");
+    if (!ok) break;
+    if (AADHip_EncodePlanRun(plan, (const int16_t *)d_pcm.p, (uint8_t *)d_data.p, (AADHipLaneState *)d_state.p) != AAD_APIRESULT_OK) break;
+    for (uint32_t i = 0; i < num_streams && ok; i++)
+      ok = hip_ok(ctx, hipMemcpyAsync(data[i], (uint8_t *)d_data.p + table[i].data_offset, sizes[i],
+                                      hipMemcpyDeviceToHost, ctx->stream), "D2H data");
+    if (!ok) break;
+    if (state && !hip_ok(ctx, hipMemcpyAsync(state, d_state.p, state_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H state")) break;
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
+    if (output_size) memcpy(output_size, sizes.data(), sizeof(uint64_t) * num_streams);
+    rc = AAD_APIRESULT_OK;
+  } while (0);
+  AADHip_EncodePlanDestroy(plan);
+  return rc;
+}
+
+/* shared by AADHip_DecodeBatch (file images) and the legacy AADDecoder_DecodeBlock (bare block) */
+AADApiResult AADHipInternal_DecodeHost(struct AADHipContext *ctx, const struct AADHeaderInfo *format,
+                                       int32_t has_file_header, uint32_t num_streams,
+                                       const uint8_t *const *data, const uint64_t *data_size,
+                                       const uint32_t *num_samples, int16_t *const *pcm, uint32_t *decoded_frames)
+{
+  std::vector<AADHipStreamDesc> table(num_streams);
+  std::vector<uint32_t> decoded(num_streams);
+  uint64_t pcm_elems = 0, data_bytes = 0;
+  const uint32_t ch = format->num_channels, head = has_file_header ? AAD_HEADER_SIZE : 0;
+  for (uint32_t i = 0; i < num_streams; i++) {
+    table[i].pcm_offset = pcm_elems;
+    table[i].data_offset = data_bytes;
+    table[i].data_size = data_size[i];
+    table[i].num_samples = num_samples[i];
+    table[i].reserved = 0;
+    pcm_elems += round_up((uint64_t)num_samples[i] * ch, 8);
+    data_bytes += round_up(data_size[i], 16);
+    /* frames the reference's block walk produces: it stops when the bytes run out (src/aad_decoder.c:514) */
+    const uint64_t payload = data_size[i] > head ? data_size[i] - head : 0;
+    const uint64_t frames = (payload + format->block_size - 1) / format->block_size * format->num_samples_per_block;
+    decoded[i] = frames < num_samples[i] ? (uint32_t)frames : num_samples[i];
+  }
+  AADHipDecodePlan *plan = nullptr;
+  AADApiResult rc = AADHip_DecodePlanCreate(ctx, format, has_file_header, num_streams, table.data(), &plan);
+  if (rc != AAD_APIRESULT_OK) return rc;
+  DeviceGuard guard(ctx);
+  DeviceBuffer d_pcm, d_data;
+  rc = AAD_APIRESULT_NG;
+  do {
+    if (!guard.ok) break;
+    if (!hip_ok(ctx, hipMalloc(&d_pcm.p, pcm_elems * sizeof(int16_t) + 64), "hipMalloc pcm")) break;
+    if (!hip_ok(ctx, hipMalloc(&d_data.p, data_bytes + 64), "hipMalloc data")) break;
+    bool ok = true;
+    for (uint32_t i = 0; i < num_streams && ok; i++)
+      ok = hip_ok(ctx, hipMemcpyAsync((uint8_t *)d_data.p + table[i].data_offset, data[i], data_size[i],
+                                      hipMemcpyHostToDevice, ctx->stream), "H2D data");
+    if (!ok) break;
+    if (AADHip_DecodePlanRun(plan, (const uint8_t *)d_data.p, (int16_t *)d_pcm.p) != AAD_APIRESULT_OK) break;
+    for (uint32_t i = 0; i < num_streams && ok; i++)
+      if (decoded[i])
+        ok = hip_ok(ctx, hipMemcpyAsync(pcm[i], (int16_t *)d_pcm.p + table[i].pcm_offset,
+                                        (size_t)decoded[i] * ch * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream), "D2H pcm");
+    if (!ok) break;
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
+    if (decoded_frames) memcpy(decoded_frames, decoded.data(), sizeof(uint32_t) * num_streams);
+    rc = AAD_APIRESULT_OK;
+  } while (0);
+  AADHip_DecodePlanDestroy(plan);
+  return rc;
+}
+
+AADApiResult AADHip_DecodeBatch(struct AADHipContext *ctx, uint32_t num_streams, const uint8_t *const *data,
+                                const uint64_t *data_size, int16_t *const *pcm, const uint32_t *pcm_capacity_frames,
+                                uint32_t *decoded_frames)
+{
+  if (ctx == nullptr || (num_streams != 0 && (data == nullptr || data_size == nullptr || pcm == nullptr ||
+      pcm_capacity_frames == nullptr)))
+    return AAD_APIRESULT_INVALID_ARGUMENT;
+  if (num_streams == 0) return AAD_APIRESULT_OK;
+  std::vector<uint32_t> frames(num_streams);
+  AADHeaderInfo format;
+  for (uint32_t i = 0; i < num_streams; i++) {
+    AADHeaderInfo h;
+    if (data[i] == nullptr || pcm[i] == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
+    if (data_size[i] < AAD_HEADER_SIZE) return AAD_APIRESULT_INSUFFICIENT_DATA;
+    if (!AADFormat_GetHeader(data[i], &h)) return AAD_APIRESULT_INVALID_FORMAT;
+    if (!AADFormat_HeaderAcceptedByDecoder(&h, AAD_HIP_MAX_NUM_CHANNELS)) return AAD_APIRESULT_INVALID_FORMAT;
+    if (i == 0) {
+      format = h;
+    } else if (h.num_channels != format.num_channels || h.bits_per_sample != format.bits_per_sample ||
+               h.block_size != format.block_size || h.num_samples_per_block != format.num_samples_per_block ||
+               h.ch_process_method != format.ch_process_method) {
+      return AAD_APIRESULT_INVALID_FORMAT; /* one format per batch */
+    }
+    if (pcm_capacity_frames[i] < h.num_samples) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
+    frames[i] = h.num_samples;
+  }
+  return AADHipInternal_DecodeHost(ctx, &format, 1, num_streams, data, data_size, frames.data(), pcm, decoded_frames);
+}
+
+} /* extern "C" */

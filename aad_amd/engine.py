@@ -1,0 +1,216 @@
+"""Python mirror of the batched C-ABI (include/aad_hip.h).
+
+torch is plumbing only: it owns the device tensors and the stream that are handed to the C
+library as raw pointers.  All codec work happens in libaad_hip.so's HIP kernels; if the library
+or a GPU is missing every call here raises - there is no fallback path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .capi import (AADApiResult, AADHeaderInfo, ApiError, LANE_STATE_DTYPE, STREAM_DESC_DTYPE,
+                   load_library, make_parameter)
+
+
+def _check(where, rc):
+    if rc != AADApiResult.OK:
+        raise ApiError(where, rc)
+
+
+def _round_up(v, a):
+    return (v + a - 1) // a * a
+
+
+class Engine:
+    """One HIP context (device + stream).  By default it rides on torch's current stream so that
+    torch.cuda.Event timing and tensor lifetimes line up with the kernels."""
+
+    def __init__(self, device=0, stream="torch", lib=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("aad_amd.Engine needs a HIP device (torch.cuda.is_available() is False)")
+        self.torch = torch
+        self.lib = lib or load_library()
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
+        if stream == "torch":
+            stream_ptr = torch.cuda.current_stream(self.device).cuda_stream
+        elif stream is None:
+            stream_ptr = None
+        else:
+            stream_ptr = int(stream)
+        self._ctx = C.c_void_p()
+        _check("AADHip_ContextCreate", self.lib.AADHip_ContextCreate(self.device, stream_ptr, C.byref(self._ctx)))
+
+    def close(self):
+        if self._ctx:
+            self.lib.AADHip_ContextDestroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return (self.lib.AADHip_ContextLastError(self._ctx) or b"").decode()
+
+    def synchronize(self):
+        _check("AADHip_ContextSynchronize", self.lib.AADHip_ContextSynchronize(self._ctx))
+
+    def encoded_size(self, param, num_samples):
+        return int(self.lib.AADHip_CalculateEncodedSize(C.byref(param), num_samples))
+
+    # ---- plans ---------------------------------------------------------------------------
+    def encode_plan(self, param, descs):
+        descs = np.ascontiguousarray(descs, dtype=STREAM_DESC_DTYPE)
+        plan = C.c_void_p()
+        _check("AADHip_EncodePlanCreate",
+               self.lib.AADHip_EncodePlanCreate(self._ctx, C.byref(param), len(descs), descs.ctypes.data, C.byref(plan)))
+        return EncodePlan(self, plan, param, descs)
+
+    def decode_plan(self, header, descs, has_file_header=True):
+        descs = np.ascontiguousarray(descs, dtype=STREAM_DESC_DTYPE)
+        plan = C.c_void_p()
+        _check("AADHip_DecodePlanCreate",
+               self.lib.AADHip_DecodePlanCreate(self._ctx, C.byref(header), 1 if has_file_header else 0, len(descs),
+                                                descs.ctypes.data, C.byref(plan)))
+        return DecodePlan(self, plan, header, descs)
+
+    # ---- uniform batches (every stream the same length) -----------------------------------
+    def uniform_encode_plan(self, param, num_streams, num_samples):
+        """Stream table for a [streams, samples, channels] int16 tensor and a [streams, stride]
+        uint8 output; stride = encoded size rounded up to 16 bytes."""
+        size = self.encoded_size(param, num_samples)
+        if size == 0:
+            raise ApiError("AADHip_CalculateEncodedSize", AADApiResult.INVALID_FORMAT)
+        stride = _round_up(size, 16)
+        d = np.zeros(num_streams, dtype=STREAM_DESC_DTYPE)
+        i = np.arange(num_streams, dtype=np.uint64)
+        d["pcm_offset"] = i * np.uint64(num_samples * param.num_channels)
+        d["data_offset"] = i * np.uint64(stride)
+        d["data_size"] = stride
+        d["num_samples"] = num_samples
+        plan = self.encode_plan(param, d)
+        plan.image_size, plan.stride = size, stride
+        return plan
+
+    def uniform_decode_plan(self, header, num_streams, stride, image_size):
+        d = np.zeros(num_streams, dtype=STREAM_DESC_DTYPE)
+        i = np.arange(num_streams, dtype=np.uint64)
+        d["pcm_offset"] = i * np.uint64(header.num_samples * header.num_channels)
+        d["data_offset"] = i * np.uint64(stride)
+        d["data_size"] = image_size
+        d["num_samples"] = header.num_samples
+        return self.decode_plan(header, d, True)
+
+    def encode_uniform(self, pcm, param, state=None):
+        """pcm: int16 cuda tensor [streams, samples, channels] -> uint8 tensor [streams, stride]
+        (each row starts with a complete .aad image of plan.image_size bytes)."""
+        torch = self.torch
+        streams, samples, ch = pcm.shape
+        assert ch == param.num_channels and pcm.dtype == torch.int16 and pcm.is_contiguous()
+        plan = self.uniform_encode_plan(param, streams, samples)
+        out = torch.zeros((streams, plan.stride), dtype=torch.uint8, device=pcm.device)
+        plan.run(pcm, out, state)
+        return out, plan.image_size
+
+    def decode_uniform(self, data, image_size):
+        """data: uint8 cuda tensor [streams, stride] of same-format images -> int16 [streams, samples, channels]"""
+        torch = self.torch
+        head = bytes(data[0, :31].cpu().numpy())
+        header = parse_header(head)
+        plan = self.uniform_decode_plan(header, data.shape[0], data.shape[1], image_size)
+        pcm = torch.zeros((data.shape[0], header.num_samples, header.num_channels), dtype=torch.int16, device=data.device)
+        plan.run(data, pcm)
+        return pcm, header
+
+    # ---- host-memory batches ----------------------------------------------------------------
+    def encode_host(self, pcm_list, param, state=None):
+        """pcm_list: list of int16 arrays [samples, channels] -> list of bytes.  state: optional
+        LANE_STATE_DTYPE array [streams * channels], updated in place."""
+        n = len(pcm_list)
+        pcm_list = [np.ascontiguousarray(p, dtype=np.int16) for p in pcm_list]
+        nsamp = np.array([p.shape[0] for p in pcm_list], dtype=np.uint32)
+        caps = np.array([max(self.encoded_size(param, int(s)), 64) for s in nsamp], dtype=np.uint64)
+        outs = [np.zeros(int(c), dtype=np.uint8) for c in caps]
+        sizes = np.zeros(n, dtype=np.uint64)
+        pp = (C.c_void_p * n)(*[p.ctypes.data for p in pcm_list])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        sp = state.ctypes.data if state is not None else None
+        _check("AADHip_EncodeBatch",
+               self.lib.AADHip_EncodeBatch(self._ctx, C.byref(param), n, pp, nsamp.ctypes.data, op,
+                                           caps.ctypes.data, sizes.ctypes.data, sp))
+        return [o[: int(s)].tobytes() for o, s in zip(outs, sizes)]
+
+    def decode_host(self, images):
+        """images: list of bytes (one format) -> list of int16 arrays [samples, channels]"""
+        n = len(images)
+        bufs = [np.frombuffer(b, dtype=np.uint8) for b in images]
+        heads = [parse_header(bytes(b[:31])) for b in images]
+        pcms = [np.zeros((h.num_samples, h.num_channels), dtype=np.int16) for h in heads]
+        sizes = np.array([len(b) for b in bufs], dtype=np.uint64)
+        caps = np.array([h.num_samples for h in heads], dtype=np.uint32)
+        got = np.zeros(n, dtype=np.uint32)
+        dp = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        pp = (C.c_void_p * n)(*[p.ctypes.data for p in pcms])
+        _check("AADHip_DecodeBatch",
+               self.lib.AADHip_DecodeBatch(self._ctx, n, dp, sizes.ctypes.data, pp, caps.ctypes.data, got.ctypes.data))
+        return pcms
+
+
+class EncodePlan:
+    def __init__(self, engine, handle, param, descs):
+        self.engine, self.handle, self.param, self.descs = engine, handle, param, descs
+        self.image_size = self.stride = None
+
+    def run(self, pcm, data, state=None):
+        """pcm: int16 cuda tensor, data: uint8 cuda tensor, state: int32 cuda tensor [lanes, 10] or None"""
+        sp = state.data_ptr() if state is not None else None
+        _check("AADHip_EncodePlanRun",
+               self.engine.lib.AADHip_EncodePlanRun(self.handle, pcm.data_ptr(), data.data_ptr(), sp))
+
+    def close(self):
+        if self.handle:
+            self.engine.lib.AADHip_EncodePlanDestroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DecodePlan:
+    def __init__(self, engine, handle, header, descs):
+        self.engine, self.handle, self.header, self.descs = engine, handle, header, descs
+
+    def run(self, data, pcm):
+        _check("AADHip_DecodePlanRun",
+               self.engine.lib.AADHip_DecodePlanRun(self.handle, data.data_ptr(), pcm.data_ptr()))
+
+    def close(self):
+        if self.handle:
+            self.engine.lib.AADHip_DecodePlanDestroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def parse_header(data):
+    """31-byte big-endian file header (reference src/aad_decoder.c:99-170) -> AADHeaderInfo"""
+    if len(data) < 31 or data[:4] != b"AAD\x00":
+        raise ApiError("parse_header", AADApiResult.INVALID_FORMAT)
+    be = lambda o, n: int.from_bytes(data[o:o + n], "big")
+    return AADHeaderInfo(format_version=be(4, 4), codec_version=be(8, 4), num_channels=be(12, 2),
+                         num_samples=be(14, 4), sampling_rate=be(18, 4), bits_per_sample=be(22, 2),
+                         block_size=be(24, 2), num_samples_per_block=be(26, 4), ch_process_method=data[30])
+
+
+__all__ = ["Engine", "EncodePlan", "DecodePlan", "parse_header", "make_parameter", "LANE_STATE_DTYPE"]

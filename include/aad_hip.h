@@ -1,0 +1,132 @@
+/*
+ * aad_hip.h - additive batched C-ABI of the MI355X AAD engine (SURVEY.md section 8b "New (additive) ABI").
+ *
+ * The reference has no batched or device-resident entry point: its only data path is one stream
+ * per call through AADEncoder_EncodeWhole (src/aad_encoder.c:814-891), AADDecoder_DecodeWhole
+ * (src/aad_decoder.c:478-538) and AADDecoder_DecodeBlock (src/aad_decoder.c:321-475).  A GPU is
+ * only useful when many independent units are in flight (encode: stream x channel; decode:
+ * block x channel), so this header exposes exactly those three loops over MANY streams:
+ *
+ *   AADHip_EncodePlanRun  == for each stream: the block loop of AADEncoder_EncodeWhole
+ *                            (EncodeHeader + [SearchBestProcessor] + EncodeBlock per block)
+ *   AADHip_DecodePlanRun  == for each stream: the block loop of AADDecoder_DecodeWhole
+ *                            (DecodeBlock per block), every block decoded independently
+ *
+ * Plain C: pointers and sizes only.  "Device" pointers are HIP device addresses (hipMalloc or
+ * any allocator sharing the HIP context, e.g. a torch tensor's data_ptr()).  The legacy
+ * AADEncoder_ / AADDecoder_ symbols are implemented on top of these with a batch of one.
+ *
+ * Device data layout
+ *   PCM   : int16, channel-interleaved frames, one contiguous run per stream.
+ *   .aad  : the exact file image per stream - 31-byte header followed by the blocks - byte for
+ *           byte what the reference writes for the same samples and parameters.
+ */
+#ifndef AAD_HIP_H_INCLUDED
+#define AAD_HIP_H_INCLUDED
+
+#include <stdint.h>
+#include "aad.h"
+#include "aad_encoder.h"
+
+#define AAD_HIP_MAX_NUM_CHANNELS 8 /* container extension; the legacy API keeps AAD_MAX_NUM_CHANNELS */
+
+struct AADHipContext;    /* device + stream + device-side tables */
+struct AADHipEncodePlan; /* uploaded stream table + launch geometry for one parameter set */
+struct AADHipDecodePlan;
+
+/* One stream of a batch.  Offsets are relative to the buffers handed to ...PlanRun. */
+struct AADHipStreamDesc {
+  uint64_t pcm_offset;  /* index of the stream's first int16 in the PCM buffer */
+  uint64_t data_offset; /* byte offset of the stream's .aad image in the data buffer */
+  uint64_t data_size;   /* encode: capacity in bytes; decode: bytes present (a short last block is fine) */
+  uint32_t num_samples; /* samples per channel */
+  uint32_t reserved;
+};
+
+/* Predictor state of one stream x channel, carried across calls exactly like the reference's
+ * struct AADEncodeProcessor (src/aad_encoder.c:10-15) inside a reused encoder handle. */
+struct AADHipLaneState {
+  int32_t weight[4];
+  int32_t history[4];
+  int32_t stepsize_index;
+  int32_t quantize_error;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* number of usable HIP devices (0 when there is none; never fails) */
+int32_t AADHip_GetDeviceCount(void);
+
+/* Create a context on `device_index`.  `hip_stream` is a hipStream_t the caller owns, or NULL
+ * to let the context create (and later destroy) its own stream.  All ...Run calls are
+ * asynchronous on that stream. */
+AADApiResult AADHip_ContextCreate(int32_t device_index, void *hip_stream, struct AADHipContext **context);
+void AADHip_ContextDestroy(struct AADHipContext *context);
+AADApiResult AADHip_ContextSynchronize(struct AADHipContext *context);
+/* text of the last HIP failure seen by this context ("" if none); valid until the next call */
+const char *AADHip_ContextLastError(const struct AADHipContext *context);
+
+/* bytes of the .aad image of a stream (header + full blocks + short tail); 0 on a bad parameter.
+ * Same arithmetic as the write_offset AADEncoder_EncodeWhole ends with (src/aad_encoder.c:881-889). */
+uint64_t AADHip_CalculateEncodedSize(const struct AADEncodeParameter *parameter, uint32_t num_samples);
+
+/* ---- encode ------------------------------------------------------------------------------ */
+
+/* Validates `parameter` like AADEncoder_SetEncodeParameter + AADEncoder_EncodeHeader would
+ * (INVALID_FORMAT), checks every stream's capacity (INSUFFICIENT_BUFFER) and uploads the table.
+ * `streams` is a host array. */
+AADApiResult AADHip_EncodePlanCreate(
+    struct AADHipContext *context, const struct AADEncodeParameter *parameter,
+    uint32_t num_streams, const struct AADHipStreamDesc *streams,
+    struct AADHipEncodePlan **plan);
+void AADHip_EncodePlanDestroy(struct AADHipEncodePlan *plan);
+
+/* Encode every stream of the plan.  device_state: NULL for fresh encoders (zero weights, zero
+ * step index), else num_streams * num_channels records read before and written after the run. */
+AADApiResult AADHip_EncodePlanRun(
+    struct AADHipEncodePlan *plan, const int16_t *device_pcm, uint8_t *device_data,
+    struct AADHipLaneState *device_state);
+
+/* ---- decode ------------------------------------------------------------------------------ */
+
+/* `format` supplies channels / bits / block geometry / channel process method for the whole
+ * batch (its num_samples field is ignored; each stream's count comes from `streams`).
+ * Validated like AADDecoder_SetHeader (src/aad_decoder.c:173-225) with the channel limit raised
+ * to AAD_HIP_MAX_NUM_CHANNELS.  has_file_header: non-zero when each image starts with the
+ * 31-byte file header (DecodeWhole), zero when data_offset points at a bare block (DecodeBlock). */
+AADApiResult AADHip_DecodePlanCreate(
+    struct AADHipContext *context, const struct AADHeaderInfo *format, int32_t has_file_header,
+    uint32_t num_streams, const struct AADHipStreamDesc *streams,
+    struct AADHipDecodePlan **plan);
+void AADHip_DecodePlanDestroy(struct AADHipDecodePlan *plan);
+
+AADApiResult AADHip_DecodePlanRun(
+    struct AADHipDecodePlan *plan, const uint8_t *device_data, int16_t *device_pcm);
+
+/* ---- host-memory convenience (stage -> run -> copy back, synchronous) ---------------------- */
+
+/* pcm[i]: num_samples[i] interleaved frames; data[i]: data_capacity[i] bytes; output_size[i]
+ * (may be NULL) receives the image size.  state: NULL for fresh encoders, else a host array of
+ * num_streams * num_channels records, read before and written after the run. */
+AADApiResult AADHip_EncodeBatch(
+    struct AADHipContext *context, const struct AADEncodeParameter *parameter,
+    uint32_t num_streams, const int16_t *const *pcm, const uint32_t *num_samples,
+    uint8_t *const *data, const uint64_t *data_capacity, uint64_t *output_size,
+    struct AADHipLaneState *state);
+
+/* data[i]/data_size[i]: .aad images (all of one format); pcm[i] must hold
+ * pcm_capacity_frames[i] >= header.num_samples frames.  decoded_frames[i] (may be NULL) receives
+ * the frames written: header.num_samples, or fewer when the image ends early - the reference's
+ * block walk stops when the bytes run out (src/aad_decoder.c:514) and so does this. */
+AADApiResult AADHip_DecodeBatch(
+    struct AADHipContext *context, uint32_t num_streams,
+    const uint8_t *const *data, const uint64_t *data_size,
+    int16_t *const *pcm, const uint32_t *pcm_capacity_frames, uint32_t *decoded_frames);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* AAD_HIP_H_INCLUDED */

@@ -1,0 +1,45 @@
+"""Shared test helpers: minimal RIFF/WAVE PCM16 reader/writer and hashing."""
+import hashlib
+import os
+import struct
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sha256(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def read_wav16(path):
+    """-> (int16 [samples, channels], rate).  Skips unknown chunks like the reference reader
+    (src/wav.c:176-193); only 16-bit PCM is needed for the fixtures."""
+    b = open(path, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:12] == b"WAVE"
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(b):
+        cid, size = b[pos:pos + 4], struct.unpack("<I", b[pos + 4:pos + 8])[0]
+        body = b[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", body[:16])
+        elif cid == b"data":
+            data = body
+            break
+        pos += 8 + size + (size & 1)
+    tag, ch, rate, _, _, bits = fmt
+    assert tag == 1 and bits == 16
+    x = np.frombuffer(data, dtype="<i2")
+    return x[: len(x) // ch * ch].reshape(-1, ch).copy(), rate
+
+
+def wav16_bytes(pcm, rate):
+    """Canonical 44-byte-header WAV image, the layout the reference writer emits
+    (src/wav.c:545-627) for 16-bit PCM."""
+    pcm = np.ascontiguousarray(pcm, dtype="<i2")
+    n, ch = pcm.shape
+    payload = pcm.tobytes()
+    head = b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 1, ch, rate, rate * 2 * ch, 2 * ch, 16) + b"data" + struct.pack("<I", len(payload))
+    return head + payload

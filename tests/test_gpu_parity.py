@@ -1,0 +1,193 @@
+"""GPU parity tests proper: the HIP engine, called through the C-ABI, against
+ (a) the reference's own fixtures and the golden hashes made from the compiled reference, and
+ (b) the CPU oracle on the same seeded inputs.
+Bar: bit-exact (integer/byte work).  Run with -m gpu on an MI355X."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import aad_amd
+import oracle_binding as ob
+from aad_amd.capi import LANE_STATE_DTYPE, make_parameter
+from aad_amd.synth import synth_pcm
+from helpers import GOLDEN, read_wav16, sha256, wav16_bytes
+
+pytestmark = pytest.mark.gpu
+FIX = os.path.join(GOLDEN, "ref_fixtures")
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import torch  # noqa: F401  (loads the HIP runtime the library then shares)
+    from aad_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def legacy():
+    import torch  # noqa: F401
+    return aad_amd.LegacyCodec(aad_amd.load_library())
+
+
+# ---- (a) reference fixtures / golden hashes -----------------------------------------------
+
+@pytest.mark.parametrize("name", ["sin300Hz_mono", "sin300Hz"])
+def test_legacy_api_reproduces_reference_fixtures(legacy, name):
+    """BASELINE config 1 through the GPU path: CLI defaults (4-bit, 1024, trials 2)."""
+    pcm, rate = read_wav16(os.path.join(FIX, name + ".wav"))
+    gold = open(os.path.join(FIX, name + ".aad"), "rb").read()
+    assert legacy.encode(pcm, 4, 1024, rate, False, 2) == gold
+    dec, hd = legacy.decode(gold)
+    assert wav16_bytes(dec, hd.sampling_rate) == open(os.path.join(FIX, name + "_decoded.wav"), "rb").read()
+
+
+def test_manifest_cases_batched(engine):
+    """Every golden case, grouped by parameter set into ragged batches (different lengths per stream)."""
+    groups = {}
+    for c in MANIFEST["cases"]:
+        groups.setdefault((c["channels"], c["bits"], c["ms"], c["trials"], c["max_block_size"]), []).append(c)
+    for (ch, bits, ms, trials, mbs), cases in groups.items():
+        pcms = [synth_pcm(1, c["samples"], ch, seed=c["seed"], kind=c["kind"])[0] for c in cases]
+        param = make_parameter(ch, bits, mbs, 48000, ms, trials)
+        images = engine.encode_host(pcms, param)
+        for c, img in zip(cases, images):
+            assert len(img) == c["aad_bytes"] and sha256(img) == c["aad_sha256"], c["name"]
+        decoded = engine.decode_host(images)
+        for c, d in zip(cases, decoded):
+            assert sha256(d.tobytes()) == c["decoded_sha256"], c["name"]
+
+
+@pytest.mark.parametrize("corpus", MANIFEST["corpora"], ids=lambda c: c["name"])
+def test_baseline_corpora_device_resident(engine, corpus):
+    """BASELINE configs 2/3/4(stereo)/5 shapes: device-resident uniform batches, hashed against the reference."""
+    import torch
+    pcm = synth_pcm(corpus["streams"], corpus["samples"], corpus["channels"], seed=corpus["seed"])
+    assert sha256(pcm.tobytes()) == corpus["pcm_sha256"]
+    param = make_parameter(corpus["channels"], corpus["bits"], corpus["max_block_size"], 48000, False, corpus["trials"])
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_img, size = engine.encode_uniform(d_pcm, param)
+    torch.cuda.synchronize()
+    assert size == corpus["image_bytes"]
+    img = d_img.cpu().numpy()
+    assert sha256(np.ascontiguousarray(img[:, :size]).tobytes()) == corpus["aad_concat_sha256"]
+    assert not img[:, size:].any()
+    d_dec, hd = engine.decode_uniform(d_img, size)
+    torch.cuda.synchronize()
+    assert sha256(d_dec.cpu().numpy().tobytes()) == corpus["decoded_concat_sha256"]
+
+
+def test_eight_channel_lanes_equal_reference_mono(engine):
+    from test_oracle_golden import extract_channel_as_mono
+    for bits in (4, 3, 2):
+        pcm = synth_pcm(4, 1000, 8, seed=77)
+        images = engine.encode_host([pcm[s] for s in range(4)], make_parameter(8, bits, 1024))
+        for s in range(4):
+            for c in range(8):
+                want = [e for e in MANIFEST["eight_channel_as_mono"]
+                        if e["bits"] == bits and e["stream"] == s and e["channel"] == c][0]
+                assert sha256(extract_channel_as_mono(images[s], c, 128)) == want["aad_sha256"]
+
+
+# ---- (b) oracle on seeded inputs ------------------------------------------------------------
+
+@pytest.mark.parametrize("bits", [4, 3, 2])
+@pytest.mark.parametrize("channels", [1, 2, 3, 8])
+def test_ragged_batch_vs_oracle(engine, bits, channels):
+    rng = np.random.default_rng(bits * 100 + channels)
+    for trials, ms, mbs in ((0, False, 1024), (2, False, 256), (1, channels == 2, 1024), (0, channels == 2, 18 * channels + 24)):
+        lens = [1, 2, 3, 4, 5, 6, 7, 12] + [int(v) for v in rng.integers(8, 5000, 40)]
+        kinds = ["music", "noise", "nyquist"]
+        pcms = [synth_pcm(1, n, channels, seed=900 + i, kind=kinds[i % 3])[0] for i, n in enumerate(lens)]
+        images = engine.encode_host(pcms, make_parameter(channels, bits, mbs, 48000, ms, trials))
+        for i, (p, img) in enumerate(zip(pcms, images)):
+            assert img == ob.encode(p, bits, mbs, 48000, ms, trials), (i, lens[i], trials, ms, mbs)
+        decoded = engine.decode_host(images)
+        for i, (img, d) in enumerate(zip(images, decoded)):
+            assert np.array_equal(d, ob.decode(img)[0]), (i, lens[i])
+
+
+def test_state_carry_matches_oracle(engine):
+    """encoder state in/out == the reference's reused-handle behaviour (src/aad_encoder.c:853-886)"""
+    ch, streams = 2, 5
+    state = np.zeros(streams * ch, dtype=LANE_STATE_DTYPE)
+    lanes = [ob.fresh_lanes(ch) for _ in range(streams)]
+    for k in range(3):
+        pcms = [synth_pcm(1, 1500 + 37 * s + k, ch, seed=10 * k + s)[0] for s in range(streams)]
+        state["stepsize_index"] = 0   # what SetEncodeParameter does between calls
+        images = engine.encode_host(pcms, make_parameter(ch, 4, 1024, 48000, False, 1), state=state)
+        for s in range(streams):
+            assert images[s] == ob.encode(pcms[s], 4, 1024, 48000, False, 1, lanes=lanes[s], reset_idx=True), (k, s)
+            for c in range(ch):
+                assert list(state[s * ch + c]["weight"]) == list(lanes[s][c].w)
+                assert int(state[s * ch + c]["stepsize_index"]) == lanes[s][c].idx
+
+
+def test_legacy_handle_reuse_and_decode_block(legacy):
+    lib = legacy.lib
+    enc = lib.AADEncoder_Create(1024, None, 0)
+    lanes = ob.fresh_lanes(2)
+    try:
+        for k in range(2):
+            pcm = synth_pcm(1, 2100 + k, 2, seed=70 + k)[0]
+            img = legacy.encode(pcm, 4, 1024, 48000, True, 2, encoder=enc)
+            assert img == ob.encode(pcm, 4, 1024, 48000, True, 2, lanes=lanes, reset_idx=True)
+    finally:
+        lib.AADEncoder_Destroy(enc)
+    hd = legacy.decode_header(img)
+    full = ob.decode(img)[0]
+    spb, bs = hd.num_samples_per_block, hd.block_size
+    for b in range(3):
+        blk = img[31 + b * bs: 31 + (b + 1) * bs]
+        want = full[b * spb:(b + 1) * spb]
+        got = legacy.decode_block(hd, blk, min(spb, len(want)))
+        assert np.array_equal(got, want), b
+    assert np.array_equal(legacy.decode_block(hd, img[31:31 + bs], 10), full[:10])   # short buffer: decode until full
+
+
+def test_truncated_image_decodes_like_block_walk(engine):
+    pcm = synth_pcm(1, 5000, 2, seed=5)[0]
+    img = ob.encode(pcm, 4, 1024)
+    cut = img[: 31 + 1024 * 2 + 500]   # third block cut short: missing bytes read as zero
+    want = np.zeros((5000, 2), dtype=np.int16)
+    buf = np.frombuffer(cut, dtype=np.uint8)
+    ob.lib().aado_decode_stream(buf.ctypes.data, len(buf), 8, want.ctypes.data, 5000, None)
+    got = engine.decode_host([cut])[0]
+    assert np.array_equal(got[: 3 * 992], want[: 3 * 992])
+
+
+def test_fp64_rmse_selection_corner(engine):
+    """int32-wrapped squares / NaN compare corner (SURVEY.md finding 5): full-scale noise and a
+    Nyquist square drive |qd| past 46341 with trials on."""
+    for kind in ("noise", "nyquist"):
+        for bits in (4, 2):
+            pcms = [synth_pcm(1, 4000, 1, seed=s, kind=kind)[0] for s in range(8)]
+            images = engine.encode_host(pcms, make_parameter(1, bits, 1024, 48000, False, 2))
+            for p, img in zip(pcms, images):
+                assert img == ob.encode(p, bits, 1024, 48000, False, 2)
+
+
+def test_plan_validation_errors(engine):
+    from aad_amd import AADApiResult as R, ApiError
+    from aad_amd.capi import STREAM_DESC_DTYPE
+    d = np.zeros(1, dtype=STREAM_DESC_DTYPE)
+    d["num_samples"], d["data_size"] = 992, 10
+    with pytest.raises(ApiError) as e:
+        engine.encode_plan(make_parameter(2, 4, 1024), d)
+    assert e.value.code == R.INSUFFICIENT_BUFFER
+    d["data_size"] = 4096
+    for bad in (make_parameter(9, 4), make_parameter(2, 1), make_parameter(2, 5), make_parameter(1, 4, ms=True),
+                make_parameter(3, 4, ms=True), make_parameter(2, 4, 20)):
+        with pytest.raises(ApiError) as e:
+            engine.encode_plan(bad, d)
+        assert e.value.code == R.INVALID_FORMAT
+    d["num_samples"] = 0
+    with pytest.raises(ApiError) as e:
+        engine.encode_plan(make_parameter(2, 4, 1024), d)
+    assert e.value.code == R.INVALID_FORMAT

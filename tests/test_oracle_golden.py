@@ -1,0 +1,98 @@
+"""Pin the oracle (oracle/aad_oracle.c) against the reference's own fixtures and against the
+golden vectors generated from the compiled reference (tests/golden/make_golden.py).
+CPU only; runs on the GPU box too (needs nothing from /root/reference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from aad_amd.synth import synth_pcm
+from helpers import GOLDEN, read_wav16, sha256, wav16_bytes
+
+FIX = os.path.join(GOLDEN, "ref_fixtures")
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+
+
+@pytest.mark.parametrize("name", ["sin300Hz_mono", "sin300Hz"])
+def test_reference_fixture_encode(name):
+    """test/make_test_data.sh:4-7 made the .aad fixtures with the CLI defaults (4-bit, 1024, trials 2)."""
+    pcm, rate = read_wav16(os.path.join(FIX, name + ".wav"))
+    gold = open(os.path.join(FIX, name + ".aad"), "rb").read()
+    assert ob.encode(pcm, bits=4, max_block_size=1024, rate=rate, trials=2) == gold
+
+
+@pytest.mark.parametrize("name", ["sin300Hz_mono", "sin300Hz"])
+def test_reference_fixture_decode(name):
+    """reference test/test_aad_decoder.c:256-339 - the suite's only bit-exact pins."""
+    gold = open(os.path.join(FIX, name + ".aad"), "rb").read()
+    pcm, hd = ob.decode(gold)
+    assert wav16_bytes(pcm, hd.sampling_rate) == open(os.path.join(FIX, name + "_decoded.wav"), "rb").read()
+
+
+def test_geometry_known_answers():
+    """reference test/test_aad_encoder.c:33-57 and SURVEY.md section 2b table"""
+    kat = {(1024, 1, 4): (1024, 2016), (1024, 2, 4): (1024, 992), (1024, 1, 3): (1023, 2684),
+           (1024, 2, 3): (1020, 1316), (1024, 1, 2): (1024, 4028), (1024, 2, 2): (1024, 1980),
+           (128, 1, 3): (126, 292), (1024, 8, 4): (1024, 224), (1024, 8, 3): (1008, 292), (1024, 8, 2): (1024, 444)}
+    for (mbs, ch, bits), want in kat.items():
+        assert ob.geometry(mbs, ch, bits) == (0,) + want
+    assert ob.geometry(17, 1, 4)[0] == 2 and ob.geometry(1024, 0, 4)[0] == 2 and ob.geometry(1024, 1, 5)[0] == 2
+
+
+def test_tables():
+    t = np.ctypeslib.as_array(ob.lib().aado_step_table(), (256,))
+    assert t[0] == 1 and t[255] == 32767 and int(t.sum()) == 864159 and np.all(np.diff(t.astype(int)) > 0)
+    assert list(np.ctypeslib.as_array(ob.lib().aado_index_deltas(4), (8,))) == [-18, -17, -14, 16, 32, 64, 128, 256]
+    assert list(np.ctypeslib.as_array(ob.lib().aado_index_deltas(3), (4,))) == [-16, -15, 32, 128]
+    assert list(np.ctypeslib.as_array(ob.lib().aado_index_deltas(2), (2,))) == [-14, 40]
+
+
+@pytest.mark.parametrize("case", MANIFEST["cases"], ids=lambda c: c["name"])
+def test_manifest_case(case):
+    pcm = synth_pcm(1, case["samples"], case["channels"], seed=case["seed"], kind=case["kind"])[0]
+    assert sha256(pcm.tobytes()) == case["pcm_sha256"], "synthetic corpus generator drifted"
+    aad = ob.encode(pcm, case["bits"], case["max_block_size"], 48000, case["ms"], case["trials"])
+    assert len(aad) == case["aad_bytes"] and sha256(aad) == case["aad_sha256"]
+    dec, _ = ob.decode(aad)
+    assert sha256(dec.tobytes()) == case["decoded_sha256"]
+    if "file" in case:
+        assert open(os.path.join(GOLDEN, case["file"]), "rb").read() == aad
+
+
+def test_eight_channel_equals_mono_lanes():
+    """an 8-channel stream's channel c carries the same header fields and
+    codes as the reference's mono encode of that channel at the matching block geometry."""
+    for bits in (4, 3, 2):
+        pcm = synth_pcm(4, 1000, 8, seed=77)
+        for s in range(4):
+            aad8 = ob.encode(pcm[s], bits, 1024)
+            for c in range(8):
+                want = [e for e in MANIFEST["eight_channel_as_mono"]
+                        if e["bits"] == bits and e["stream"] == s and e["channel"] == c][0]
+                assert sha256(extract_channel_as_mono(aad8, c, 128)) == want["aad_sha256"]
+
+
+def extract_channel_as_mono(aad, c, mono_max_block_size):
+    """Re-frame channel c of a multi-channel image as the mono image with the same samples/block."""
+    import math
+    hd = ob.AadoHeader()
+    buf = np.frombuffer(aad, dtype=np.uint8)
+    assert ob.lib().aado_get_header(buf.ctypes.data, len(buf), hd) == 0
+    ch, bits = hd.num_channels, hd.bits_per_sample
+    rc, mono_bs, mono_spb = ob.geometry(mono_max_block_size, 1, bits)
+    assert rc == 0 and mono_spb == hd.samples_per_block
+    ub = math.lcm(8, bits) // 8
+    out = bytearray(aad[:31])
+    out[12:14] = (1).to_bytes(2, "big")
+    out[24:26] = mono_bs.to_bytes(2, "big")
+    pos = 31
+    while pos < len(aad):
+        blk = aad[pos:pos + hd.block_size]
+        out += blk[18 * c:18 * (c + 1)]
+        body = blk[18 * ch:]
+        for u in range(len(body) // (ub * ch)):
+            out += body[(u * ch + c) * ub:(u * ch + c + 1) * ub]
+        pos += hd.block_size
+    return bytes(out)
