@@ -5,20 +5,36 @@
  *   encode: lane = (stream, channel) - blocks of a stream are chained through the predictor
  *           state (SURVEY.md finding 2), so a stream is the smallest independent unit;
  *   decode: lane = (block, channel)  - every block header reloads the whole state.
- * The whole per-channel state (4 weights, 4 history samples, step index) lives in VGPRs; the
- * 256-entry step table sits in LDS next to fl32(0.5/step) so that the quantiser's division is a
- * convert-multiply-truncate (proved equal to the reference's integer division over every
- * reachable operand in tests/test_quantiser_equiv.py).  There is no contraction anywhere, hence
- * no MFMA: the kernels are integer VALU work streaming int16 PCM in and packed codes out.
+ * Adjacent lanes are the channels of one stream/block, so the bytes they touch are adjacent.
  *
- * Arithmetic widths follow SURVEY.md finding 5: int32 wraparound (done in unsigned), arithmetic
- * right shifts, 24-bit multiplies only where both operands provably fit.
+ * What bounds these kernels (measured, tools/microbench): a gfx950 wave issues one instruction
+ * per ~4.2-5.2 cycles whatever the instruction (VALU, SALU, LDS, 32-bit multiplies included)
+ * and every BASELINE workload has far fewer lanes than the chip has SIMD slots.  The lever is
+ * therefore the NUMBER of instructions on the per-sample path, not their kind:
+ *   - the whole per-channel state (4 weights, 4 history samples, step index) lives in VGPRs,
+ *     history rotation is free because samples are processed in unrolled chunks of 16;
+ *   - the step table sits in LDS as 16-byte records {step, fl32(0.5/step), fl32(2^(b-1)*0.5/step)}
+ *     addressed by (index & 0xFF0): one v_and + one ds_read_b128;
+ *   - the quantiser's integer division is  min(trunc(fma(|d|, hs, hr)), magmax)  - convert, fma
+ *     with |.| source modifier, convert, min - proved equal to the reference's division for
+ *     every reachable operand (tests/test_quantiser_equiv.py);
+ *   - the step-index delta is one ds_read_i16 addressed by the odd number 2*mag+1 that the
+ *     dequantiser needs anyway;
+ *   - predict is a v_mad_i32_i24 chain while the weights provably fit 24 bits (checked once per
+ *     chunk; real audio stays below 2^17) with an exact 32-bit-multiply twin for any weights;
+ *     the LMS products always use v_mad_i32_i24 (|qd| <= 61438, |h| <= 32768: exact);
+ *   - code bytes are read/written in wide unaligned accesses per 16-sample chunk; the stereo
+ *     L/R byte interleave is one DPP lane swap plus v_perm_b32 byte permutes.
+ * There is no contraction anywhere, hence no MFMA.
+ *
+ * Arithmetic widths follow SURVEY.md finding 5: int32 wraparound, arithmetic right shifts.
  */
 #ifndef AAD_DEVICE_HIP_H
 #define AAD_DEVICE_HIP_H
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "aad_tables_data.h"
 
@@ -27,15 +43,31 @@ namespace aad {
 constexpr int kTaps = 4;
 constexpr int kBlockHeaderBytesPerCh = 18;
 constexpr int kFileHeaderBytes = 31;
-constexpr int kIndexMax = AAD_STEP_INDEX_MAX;
+constexpr int kChunk = 16; /* samples per unrolled chunk: a multiple of every pack unit (2, 8, 4) and of the tap count */
 
-struct StepEntry {
-  int32_t step;
-  float half_recip; /* fl32(0.5 / step) */
-};
+/* the step index is kept biased by +8 so that (index & 0xFF0) is the byte offset of its table record */
+constexpr int kIdxBias = 8;
+constexpr int kIdxMin = kIdxBias, kIdxMax = AAD_STEP_INDEX_MAX + kIdxBias;
+
+/* LDS image: 256 x 16-byte step records, then the index deltas of this bit width as int16 */
+constexpr int kLdsStepBytes = AAD_STEP_TABLE_LEN * 16;
+constexpr int kLdsDeltaOff = kLdsStepBytes;
+constexpr int kLdsBytes = kLdsStepBytes + 16;
 
 __constant__ uint16_t c_step_table[AAD_STEP_TABLE_LEN] = {AAD_STEP_TABLE_VALUES};
 __constant__ uint32_t c_half_recip_bits[AAD_STEP_TABLE_LEN] = {AAD_HALF_RECIP_BITS};
+__constant__ int16_t c_delta4[8] = {AAD_INDEX_DELTA_4BIT};
+__constant__ int16_t c_delta3[4] = {AAD_INDEX_DELTA_3BIT};
+__constant__ int16_t c_delta2[2] = {AAD_INDEX_DELTA_2BIT};
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(1))) U32 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U32x2 { u32x2 v; };
+struct __attribute__((packed, aligned(1))) U32x3 { u32x3 v; };
+struct __attribute__((packed, aligned(1))) U32x4 { u32x4 v; };
+struct __attribute__((packed, aligned(1))) U16 { uint16_t v; };
 
 /* mirrors struct AADHipStreamDesc (include/aad_hip.h) */
 struct StreamDesc {
@@ -57,26 +89,84 @@ struct LaneStateRecord {
 struct Lane {
   int32_t w0, w1, w2, w3; /* Q15 LMS weights */
   int32_t h0, h1, h2, h3; /* history, h0 newest */
-  int32_t idx;            /* Q4 step index */
+  int32_t idxb;           /* Q4 step index + kIdxBias */
 };
 
-/* stage the step table into LDS; every thread of the workgroup must call this */
-__device__ __forceinline__ void stage_step_table(StepEntry *tab)
+/* compile-time unrolled loop: f(std::integral_constant<int, I>) for I in [I0, N) */
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int BITS>
+struct Pack {
+  static constexpr int kUnitSamples = BITS == 3 ? 8 : (BITS == 4 ? 2 : 4);
+  static constexpr int kUnitBytes = BITS == 3 ? 3 : 1;
+  static constexpr int kChunkBytes = kChunk * BITS / 8;                 /* per channel: 8 / 6 / 4 */
+  static constexpr int kWords = BITS == 2 ? 1 : 2;                      /* code words per chunk */
+  static constexpr int kCodesPerWord = kChunk / kWords;                 /* 8 / 8 / 16 */
+  static constexpr uint32_t kSign = 1u << (BITS - 1), kMagMax = kSign - 1u;
+  /* bit position of code j (0 = oldest) inside its big-endian code word */
+  static constexpr int pos(int j) { return BITS * (kCodesPerWord - 1 - j); }
+};
+
+/* stage the tables into LDS; every thread of the workgroup must call this */
+template <int BITS>
+__device__ __forceinline__ void stage_tables(char *lds)
 {
   for (int i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) {
-    StepEntry e;
-    e.step = c_step_table[i];
-    e.half_recip = __uint_as_float(c_half_recip_bits[i]);
-    tab[i] = e;
+    const float hr = __uint_as_float(c_half_recip_bits[i]);
+    u32x4 e;
+    e.x = c_step_table[i];
+    e.y = __float_as_uint(hr);
+    e.z = __float_as_uint(hr * (float)(1 << (BITS - 1))); /* exact power-of-two scaling */
+    e.w = 0;
+    *reinterpret_cast<u32x4 *>(lds + i * 16) = e;
+  }
+  if (threadIdx.x < 8) {
+    int16_t d = 0;
+    if (BITS == 4) d = c_delta4[threadIdx.x & 7];
+    if (BITS == 3) d = c_delta3[threadIdx.x & 3];
+    if (BITS == 2) d = c_delta2[threadIdx.x & 1];
+    reinterpret_cast<int16_t *>(lds + kLdsDeltaOff)[threadIdx.x] = d;
   }
   __syncthreads();
 }
 
 __device__ __forceinline__ int32_t clip16(int32_t v) { return min(max(v, -32768), 32767); }
 
-/* (16384 + sum h*w) >> 15 with int32 wraparound - reference src/aad_encoder.c:359-363 */
+/* a*b + c on the 24-bit multiplier (v_mad_i32_i24).  Both operands MUST fit 24 signed bits; the
+ * explicit sign extensions tell the compiler so and cost nothing (the instruction ignores the
+ * upper byte).  Native code rather than inline asm: the hazard recogniser pads every asm result
+ * with an s_nop, and a wave pays ~4 cycles for each. */
+__device__ __forceinline__ int32_t sx24(int32_t v) { return (int32_t)((uint32_t)v << 8) >> 8; }
+__device__ __forceinline__ int32_t opaque(int32_t v)
+{
+  asm("" : "+v"(v)); /* emits nothing; only hides the value from reassociation */
+  return v;
+}
+__device__ __forceinline__ int32_t mad_i24(int32_t a, int32_t b, int32_t c)
+{
+  return (int32_t)((uint32_t)(sx24(a) * sx24(b)) + (uint32_t)c);
+}
+
+/* (16384 + sum h*w) >> 15 with int32 wraparound - reference src/aad_encoder.c:359-363.
+ * FAST24: the caller has checked |w| < 2^23 for the whole chunk, so the 24-bit multiplier gives
+ * the exact products; otherwise full 32-bit multiplies (exact for ANY weights). */
+template <bool FAST24>
 __device__ __forceinline__ int32_t predict(const Lane &L)
 {
+  if (FAST24) { /* a chain of four v_mad_i32_i24; opaque() stops the compiler from turning it into 4 mul + 2 add3 */
+    int32_t acc = mad_i24(L.h0, L.w0, 16384);
+    acc = mad_i24(L.h1, L.w1, opaque(acc));
+    acc = mad_i24(L.h2, L.w2, opaque(acc));
+    acc = mad_i24(L.h3, L.w3, opaque(acc));
+    return acc >> 15;
+  }
   uint32_t acc = 16384u;
   acc += (uint32_t)L.h0 * (uint32_t)L.w0;
   acc += (uint32_t)L.h1 * (uint32_t)L.w1;
@@ -85,32 +175,24 @@ __device__ __forceinline__ int32_t predict(const Lane &L)
   return (int32_t)acc >> 15;
 }
 
-/* Q4 step-index delta of a magnitude code - the constants of reference src/aad_tables.c:8-45
- * (AAD_INDEX_DELTA_*BIT in aad_tables_data.h) folded into selects: 4-bit {-18,-17,-14,16,32,64,128,256},
- * 3-bit {-16,-15,32,128}, 2-bit {-14,40}. */
-template <int BITS>
-__device__ __forceinline__ int32_t index_delta(uint32_t mag)
+/* Per-step weight change is at most (61438 * 32768 + 16384) >> 18 = 7680 < 2^13, so weights that
+ * start a 16-sample chunk below 2^22 in magnitude stay below 2^23 throughout it. */
+__device__ __forceinline__ bool weights_fit_24(const Lane &L)
 {
-  if (BITS == 4) {
-    const int32_t low = mag == 0 ? -18 : (mag == 1 ? -17 : -14);
-    return mag >= 3 ? (int32_t)(2u << mag) : low;
-  } else if (BITS == 3) {
-    return mag >= 2 ? (mag == 2 ? 32 : 128) : (int32_t)mag - 16;
-  } else {
-    return mag ? 40 : -14;
-  }
+  constexpr uint32_t T = 1u << 22;
+  return (((uint32_t)L.w0 + T) | ((uint32_t)L.w1 + T) | ((uint32_t)L.w2 + T) | ((uint32_t)L.w3 + T)) < 2u * T;
 }
 
 /* step-index, LMS and history update - reference src/aad_encoder.c:386-406, src/aad_decoder.c:303-315.
- * qd*h fits 32 bits (|qd| <= 61438, |h| <= 32768), so the 24-bit multiplier is exact. */
-template <int BITS>
-__device__ __forceinline__ void advance(Lane &L, uint32_t mag, int32_t qd, int32_t y)
+ * m21 = 2*mag + 1 addresses the int16 delta table: byte offset 2*mag = m21 - 1. */
+__device__ __forceinline__ void advance(Lane &L, uint32_t m21, int32_t qd, int32_t y, const char *lds)
 {
-  L.idx = min(max(L.idx + index_delta<BITS>(mag), 0), kIndexMax);
-  L.w0 = (int32_t)((uint32_t)L.w0 + (uint32_t)((__mul24(qd, L.h0) + 16384) >> 18));
-  L.w1 = (int32_t)((uint32_t)L.w1 + (uint32_t)((__mul24(qd, L.h1) + 16384) >> 18));
-  L.w2 = (int32_t)((uint32_t)L.w2 + (uint32_t)((__mul24(qd, L.h2) + 16384) >> 18));
-  L.w3 = (int32_t)((uint32_t)L.w3 + (uint32_t)((__mul24(qd, L.h3) + 16384) >> 18));
+  const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDeltaOff - 1) + m21);
+  L.idxb = min(max(L.idxb + delta, kIdxMin), kIdxMax);
+  L.w0 += mad_i24(qd, L.h0, 16384) >> 18;
+  L.w1 += mad_i24(qd, L.h1, 16384) >> 18;
+  L.w2 += mad_i24(qd, L.h2, 16384) >> 18;
+  L.w3 += mad_i24(qd, L.h3, 16384) >> 18;
   L.h3 = L.h2;
   L.h2 = L.h1;
   L.h1 = L.h0;
@@ -119,44 +201,49 @@ __device__ __forceinline__ void advance(Lane &L, uint32_t mag, int32_t qd, int32
 
 /* one encoder step - reference src/aad_encoder.c:343-410.  Returns the code; qd is the
  * dequantised difference (the reference's quantize_error). */
-template <int BITS>
-__device__ __forceinline__ uint32_t encode_step(Lane &L, int32_t x, const StepEntry *tab, int32_t &qd)
+template <int BITS, bool FAST24>
+__device__ __forceinline__ uint32_t encode_step(Lane &L, int32_t x, const char *lds, int32_t &qd)
 {
-  constexpr uint32_t kSign = 1u << (BITS - 1), kMagMax = kSign - 1u;
-  const StepEntry e = tab[(L.idx + 8) >> 4];
-  const int32_t p = predict(L);
+  const u32x4 e = *reinterpret_cast<const u32x4 *>(lds + (L.idxb & 0xFF0));
+  const int32_t p = predict<FAST24>(L);
   const int32_t d = x - p;
   const int32_t m = d >> 31; /* 0 or -1 */
-  const uint32_t a = (uint32_t)((d ^ m) - m);
-  /* min((a << (BITS-2)) / step, magmax) as trunc(fl32(2*(a << (BITS-2)) + 1) * fl32(0.5/step)) */
-  const uint32_t a2 = (a << (BITS - 1)) | 1u;
-  const uint32_t mag = min((uint32_t)((float)a2 * e.half_recip), kMagMax);
-  const int32_t q = (int32_t)(__umul24((uint32_t)e.step, 2u * mag + 1u) >> (BITS - 1));
+  /* min((|d| << (BITS-2)) / step, magmax) == min(trunc(fma(|d|, 2^(BITS-1)*hr, hr)), magmax), hr = fl32(0.5/step) */
+  const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf((float)d), __uint_as_float(e.z), __uint_as_float(e.y)),
+                           Pack<BITS>::kMagMax);
+  const uint32_t m21 = (mag << 1) | 1u;
+  const int32_t q = (int32_t)(__umul24(e.x, m21) >> (BITS - 1));
   qd = (q ^ m) - m;
-  advance<BITS>(L, mag, qd, clip16(qd + p));
-  return mag | ((uint32_t)m & kSign);
+  advance(L, m21, qd, clip16(qd + p), lds);
+  return mag | ((uint32_t)m & Pack<BITS>::kSign);
 }
 
-/* one decoder step - reference src/aad_decoder.c:269-318 */
-template <int BITS>
-__device__ __forceinline__ int32_t decode_step(Lane &L, uint32_t code, const StepEntry *tab)
+/* one decoder step - reference src/aad_decoder.c:269-318.  `word` holds big-endian packed codes,
+ * POS is the bit position of this sample's code in it. */
+template <int BITS, int POS, bool FAST24>
+__device__ __forceinline__ int32_t decode_step(Lane &L, uint32_t word, const char *lds)
 {
-  constexpr uint32_t kSign = 1u << (BITS - 1), kMagMax = kSign - 1u;
-  const int32_t step = tab[(L.idx + 8) >> 4].step;
-  const uint32_t mag = code & kMagMax;
-  const int32_t q = (int32_t)(__umul24((uint32_t)step, 2u * mag + 1u) >> (BITS - 1));
-  const int32_t m = -(int32_t)((code >> (BITS - 1)) & 1u);
+  const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + (L.idxb & 0xFF0));
+  constexpr uint32_t kMask2 = Pack<BITS>::kMagMax << 1;
+  const uint32_t m21 = ((POS >= 1 ? word >> (POS >= 1 ? POS - 1 : 0) : word << 1) & kMask2) | 1u;
+  const int32_t m = (int32_t)(word << (31 - (POS + BITS - 1))) >> 31;
+  const int32_t q = (int32_t)(__umul24(step, m21) >> (BITS - 1));
   const int32_t qd = (q ^ m) - m;
-  const int32_t y = clip16(qd + predict(L));
-  advance<BITS>(L, mag, qd, y);
+  const int32_t y = clip16(qd + predict<FAST24>(L));
+  advance(L, m21, qd, y, lds);
   return y;
 }
 
-template <int BITS>
-struct Pack {
-  static constexpr int kUnitSamples = BITS == 3 ? 8 : (BITS == 4 ? 2 : 4);
-  static constexpr int kUnitBytes = BITS == 3 ? 3 : 1;
-};
+/* ---- per-lane byte shuffles ------------------------------------------------------------- */
+
+/* v_perm_b32: selector bytes 0-3 pick from `lo`, 4-7 from `hi`, 0x0c yields 0x00 */
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+/* value of the neighbouring lane (lane ^ 1): the other channel of a stereo pair */
+__device__ __forceinline__ uint32_t pair_swap(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+}
 
 /* ================================================================================ decode == */
 
@@ -188,21 +275,61 @@ __device__ __forceinline__ uint32_t find_stream(const uint64_t *prefix, uint32_t
 
 __device__ __forceinline__ uint32_t load_be16(const uint8_t *p) { return ((uint32_t)p[0] << 8) | p[1]; }
 
+/* Code words of one 16-sample chunk of channel c.  CHF = 1 or 2 channels (fast paths: one wide
+ * unaligned load, per-lane v_perm selectors pull the lane's own bytes out of the L/R interleave
+ * and turn them big-endian).  `p` points at the first byte of the chunk's first unit of channel 0. */
+template <int BITS, int CHF>
+struct ChunkCodes {
+  uint32_t w[2];
+  /* bytes the wide load touches, measured from p */
+  static constexpr int kLoadBytes = CHF == 1 ? (BITS == 2 ? 4 : 8) : (BITS == 4 ? 16 : (BITS == 3 ? 12 : 8));
+  __device__ __forceinline__ void load(const uint8_t *p, uint32_t c)
+  {
+    if (CHF == 1) {
+      if (BITS == 2) {
+        w[0] = perm(0, reinterpret_cast<const U32 *>(p)->v, 0x00010203);
+      } else {
+        const u32x2 d = reinterpret_cast<const U32x2 *>(p)->v;
+        if (BITS == 4) {
+          w[0] = perm(0, d.x, 0x00010203);
+          w[1] = perm(0, d.y, 0x00010203);
+        } else { /* two 3-byte units */
+          w[0] = perm(d.y, d.x, 0x0c000102);
+          w[1] = perm(d.y, d.x, 0x0c030405);
+        }
+      }
+    } else {
+      if (BITS == 4) { /* L R L R ...: own bytes c, c+2 of every dword */
+        const u32x4 d = reinterpret_cast<const U32x4 *>(p)->v;
+        const uint32_t sel = 0x00020406u + c * 0x01010101u;
+        w[0] = perm(d.y, d.x, sel);
+        w[1] = perm(d.w, d.z, sel);
+      } else if (BITS == 2) {
+        const u32x2 d = reinterpret_cast<const U32x2 *>(p)->v;
+        w[0] = perm(d.y, d.x, 0x00020406u + c * 0x01010101u);
+      } else { /* L3 R3 L3 R3 */
+        const u32x3 d = reinterpret_cast<const U32x3 *>(p)->v;
+        w[0] = perm(d.y, d.x, c ? 0x0c030405u : 0x0c000102u);
+        w[1] = perm(d.z, d.y, c ? 0x0c050607u : 0x0c020304u);
+      }
+    }
+  }
+};
+
 /*
  * Block-parallel decode (reference src/aad_decoder.c:321-475, looped by :514-534).
- * lane = (global block, channel); adjacent lanes are the channels of one block so the packed
- * units they read are adjacent bytes and the frames they write are adjacent int16.
+ * CHF: 1 / 2 = specialised channel counts with wide chunk loads, 0 = any channel count (byte loads).
  */
-template <int BITS>
-__global__ void __launch_bounds__(64) decode_blocks_kernel(DecodeArgs a)
+template <int BITS, int CHF, bool MS>
+__global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
 {
-  __shared__ StepEntry tab[AAD_STEP_TABLE_LEN];
-  stage_step_table(tab);
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  stage_tables<BITS>(lds);
 
-  const uint32_t ch = a.channels;
+  const uint32_t ch = CHF ? CHF : a.channels;
   const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = lane < a.total_blocks * ch;
-  uint64_t g = active ? lane / ch : 0;
+  const uint64_t g = active ? lane / ch : 0;
   const uint32_t c = active ? (uint32_t)(lane % ch) : 0;
 
   const uint32_t s = find_stream(a.block_prefix, a.num_streams, g);
@@ -216,16 +343,17 @@ __global__ void __launch_bounds__(64) decode_blocks_kernel(DecodeArgs a)
   }
   /* bytes of this stream still present from the start of this block */
   const uint64_t block_off = a.header_bytes + b * a.block_size;
-  const uint64_t avail = sd.data_size > block_off ? sd.data_size - block_off : 0;
+  const uint64_t avail64 = sd.data_size > block_off ? sd.data_size - block_off : 0;
+  const uint32_t avail = avail64 > 0x7FFFFFFFu ? 0x7FFFFFFFu : (uint32_t)avail64;
   const uint8_t *src = a.data + sd.data_offset + block_off;
   int16_t *dst = a.pcm + sd.pcm_offset + first * ch + c;
-  if (avail < (uint64_t)kBlockHeaderBytesPerCh * ch) n = 0; /* DecodeBlock: INSUFFICIENT_DATA (host reports it) */
+  if (avail < (uint32_t)kBlockHeaderBytesPerCh * ch) n = 0; /* DecodeBlock: INSUFFICIENT_DATA (reported by the host) */
 
-  Lane L = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (n) {
+  Lane L = {0, 0, 0, 0, 0, 0, 0, 0, kIdxBias};
+  if (n) { /* block header - reference src/aad_decoder.c:364-380 */
     const uint8_t *hp = src + c * kBlockHeaderBytesPerCh;
     const uint32_t v = load_be16(hp);
-    L.idx = min((int32_t)(v >> 4), kIndexMax);
+    L.idxb = min((int32_t)(v >> 4), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias;
     const uint32_t shift = v & 0xFu;
     L.w0 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 2) << shift);
     L.h0 = (int16_t)load_be16(hp + 4);
@@ -237,32 +365,79 @@ __global__ void __launch_bounds__(64) decode_blocks_kernel(DecodeArgs a)
     L.h3 = (int16_t)load_be16(hp + 16);
   }
 
-  const bool ms = a.mid_side != 0; /* host guarantees ch == 2 then */
-  auto emit = [&](uint32_t i, int32_t y) {
-    if (ms) {
-      const int32_t other = __shfl_xor(y, 1);
-      y = c == 0 ? clip16(y + other) : clip16(other - y);
+  /* inverse mid/side needs the partner channel's sample: lanes c=0/1 of a block are neighbours
+   * and run the same trip counts, so the swap always meets an active lane */
+  auto finish = [&](int32_t y) -> int32_t {
+    if (MS) {
+      const int32_t other = (int32_t)pair_swap((uint32_t)y);
+      return c == 0 ? clip16(y + other) : clip16(other - y);
     }
-    if (i < n) dst[(uint64_t)i * ch] = (int16_t)y;
+    return y;
   };
+
   /* the first four samples are stored verbatim in the header - reference :386-391 */
-  emit(0, L.h3);
-  emit(1, L.h2);
-  emit(2, L.h1);
-  emit(3, L.h0);
+  {
+    const int32_t y0 = finish(L.h3), y1 = finish(L.h2), y2 = finish(L.h1), y3 = finish(L.h0);
+    if (n > 0) dst[0] = (int16_t)y0;
+    if (n > 1) dst[ch] = (int16_t)y1;
+    if (n > 2) dst[2 * ch] = (int16_t)y2;
+    if (n > 3) dst[3 * ch] = (int16_t)y3;
+  }
 
   constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
-  const uint64_t unit_base = (uint64_t)kBlockHeaderBytesPerCh * ch + (uint64_t)c * UB;
-  const uint32_t unit_stride = UB * ch;
-  for (uint32_t i = kTaps, u = 0; i < n; i += US, u++) {
-    const uint64_t o = unit_base + (uint64_t)u * unit_stride;
-    uint32_t acc = 0;
+  const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
+  uint32_t done = 0; /* coded samples finished */
+
+  if (CHF != 0) {
+    /* full 16-sample chunks whose wide load stays inside the stream's bytes */
+    using CC = ChunkCodes<BITS, (CHF ? CHF : 1)>;
+    constexpr uint32_t kStride = Pack<BITS>::kChunkBytes * (CHF ? CHF : 1);
+    const uint32_t body = (uint32_t)kBlockHeaderBytesPerCh * ch;
+    uint32_t full = coded / kChunk;
+    if (avail < body + CC::kLoadBytes) {
+      full = 0;
+    } else {
+      const uint32_t fit = (avail - body - CC::kLoadBytes) / kStride + 1;
+      full = full < fit ? full : fit;
+    }
+    const uint8_t *cp = src + body;
+    int16_t *op = dst + (uint64_t)kTaps * ch;
+    CC next;
+    if (full) next.load(cp, c);
+    for (uint32_t k = 0; k < full; k++) {
+      const CC cur = next;
+      cp += kStride;
+      if (k + 1 < full) next.load(cp, c); /* prefetch the next chunk under this one's arithmetic */
+      auto body = [&](auto fast) {
+        static_for<0, kChunk>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int cpw = Pack<BITS>::kCodesPerWord;
+          const int32_t y = decode_step<BITS, Pack<BITS>::pos(j % cpw), decltype(fast)::value>(L, cur.w[j / cpw], lds);
+          op[(uint32_t)j * ch] = (int16_t)finish(y);
+        });
+      };
+      if (weights_fit_24(L)) body(std::true_type{}); else body(std::false_type{});
+      op += (uint64_t)kChunk * ch;
+    }
+    done = full * kChunk;
+  }
+
+  /* remaining units (all of them when CHF == 0): byte loads, bytes past the stream read as zero */
+  {
+    const uint32_t unit_stride = UB * ch;
+    const uint32_t base = (uint32_t)kBlockHeaderBytesPerCh * ch + c * UB;
+    for (uint32_t i = done; i < coded; i += US) {
+      const uint32_t o = base + (i / US) * unit_stride;
+      uint32_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < UB; k++) acc = (acc << 8) | (o + k < avail ? (uint32_t)src[o + k] : 0u);
+      for (int k = 0; k < UB; k++) acc = (acc << 8) | (o + k < avail ? (uint32_t)src[o + k] : 0u);
+      acc <<= 32 - 8 * UB; /* codes to the top of the word */
 #pragma unroll
-    for (int k = 0; k < US; k++) {
-      const uint32_t code = (acc >> (BITS * (US - 1 - k))) & ((1u << BITS) - 1u);
-      emit(i + k, decode_step<BITS>(L, code, tab));
+      for (int k = 0; k < US; k++) {
+        const int32_t y = finish(decode_step<BITS, 32 - BITS, false>(L, acc, lds));
+        acc <<= BITS;
+        if (i + k < coded) dst[(uint64_t)(kTaps + i + k) * ch] = (int16_t)y;
+      }
     }
   }
 }
@@ -286,12 +461,13 @@ struct EncodeArgs {
 
 /* sample i of channel c of a stream, after the optional L/R -> M/S transform
  * (reference src/aad_encoder.c:413-428; the clip there can never trigger for int16 input) */
+template <bool MS>
 struct SampleSource {
   const int16_t *x;
-  uint32_t ch, c, ms;
+  uint32_t ch, c;
   __device__ __forceinline__ int32_t at(uint64_t i) const
   {
-    if (ms) {
+    if (MS) {
       const int32_t l = x[i * 2], r = x[i * 2 + 1];
       return c == 0 ? (l + r) >> 1 : (l - r) >> 1;
     }
@@ -299,7 +475,44 @@ struct SampleSource {
   }
 };
 
-__device__ __forceinline__ void seed_history(Lane &L, const SampleSource &src, uint64_t first, uint32_t n)
+/* 16 consecutive samples of channel c starting at frame `first`, fetched with wide loads.
+ * CHF = 1: 32 contiguous bytes; CHF = 2: 64 bytes of L/R frames (both lanes of the pair read
+ * the same bytes and keep their own half); CHF = 0: 16 strided int16 loads. */
+template <int CHF, bool MS>
+struct ChunkSamples {
+  uint32_t d[CHF == 1 ? 8 : 16];
+  __device__ __forceinline__ void load(const int16_t *x, uint32_t ch, uint32_t c)
+  {
+    if (CHF == 1) {
+      const u32x4 a = reinterpret_cast<const U32x4 *>(x)->v, b = reinterpret_cast<const U32x4 *>(x + 8)->v;
+      d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    } else if (CHF == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32x4 a = reinterpret_cast<const U32x4 *>(x + 8 * k)->v;
+        d[4 * k] = a.x; d[4 * k + 1] = a.y; d[4 * k + 2] = a.z; d[4 * k + 3] = a.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) d[k] = (uint32_t)(int32_t)x[(uint32_t)k * ch + c];
+    }
+  }
+  __device__ __forceinline__ int32_t get(int j, uint32_t c) const
+  {
+    if (CHF == 1) return __builtin_amdgcn_sbfe((int32_t)d[j >> 1], (j & 1) * 16, 16);
+    if (CHF == 2) {
+      if (MS) {
+        const int32_t l = __builtin_amdgcn_sbfe((int32_t)d[j], 0, 16), r = (int32_t)d[j] >> 16;
+        return c == 0 ? (l + r) >> 1 : (l - r) >> 1;
+      }
+      return __builtin_amdgcn_sbfe((int32_t)d[j], c * 16, 16);
+    }
+    return (int32_t)d[j];
+  }
+};
+
+template <typename Src>
+__device__ __forceinline__ void seed_history(Lane &L, const Src &src, uint64_t first, uint32_t n)
 {
   L.h3 = n > 0 ? src.at(first + 0) : 0;
   L.h2 = n > 1 ? src.at(first + 1) : 0;
@@ -311,33 +524,33 @@ __device__ __forceinline__ void seed_history(Lane &L, const SampleSource &src, u
  * reference src/aad_encoder.c:431-467.  The squares wrap in int32 like the reference's
  * (SURVEY.md finding 5); every partial sum is an exact integer < 2^53, so accumulating in
  * int64 and converting once equals the reference's running double sum. */
-template <int BITS>
-__device__ __forceinline__ double rmse_pass(Lane &L, const SampleSource &src, uint64_t first, uint32_t n,
-                                            const StepEntry *tab)
+template <int BITS, typename Src>
+__device__ __forceinline__ double rmse_pass(Lane &L, const Src &src, uint64_t first, uint32_t n,
+                                            const char *lds)
 {
   if (n < (uint32_t)kTaps) return 0.0;
   seed_history(L, src, first, n);
   int64_t sum = 0;
   for (uint32_t i = kTaps; i < n; i++) {
     int32_t qd;
-    encode_step<BITS>(L, src.at(first + i), tab, qd);
+    encode_step<BITS, false>(L, src.at(first + i), lds, qd);
     sum += (int64_t)(int32_t)((uint32_t)qd * (uint32_t)qd);
   }
   return sqrt((double)sum / (double)n);
 }
 
 /* trial search - reference src/aad_encoder.c:470-562 (per channel; channels are independent) */
-template <int BITS>
-__device__ __forceinline__ void search_best_lane(Lane &L, const SampleSource &src, uint64_t first, uint32_t n,
-                                                 uint32_t spb, uint32_t trials, const StepEntry *tab)
+template <int BITS, typename Src>
+__device__ __forceinline__ void search_best_lane(Lane &L, const Src &src, uint64_t first, uint32_t n,
+                                                 uint32_t spb, uint32_t trials, const char *lds)
 {
   const bool have_prev = first >= spb;
   Lane best = L, run = L, probe = L;
-  double best_rmse = rmse_pass<BITS>(probe, src, first, n, tab);
+  double best_rmse = rmse_pass<BITS>(probe, src, first, n, lds);
   for (uint32_t t = 0; t < trials; t++) {
-    if (have_prev) (void)rmse_pass<BITS>(run, src, first - spb, spb, tab);
+    if (have_prev) (void)rmse_pass<BITS>(run, src, first - spb, spb, lds);
     const Lane cand = run;
-    const double r = rmse_pass<BITS>(run, src, first, n, tab);
+    const double r = rmse_pass<BITS>(run, src, first, n, lds);
     if (best_rmse > r) {
       best_rmse = r;
       best = cand;
@@ -364,7 +577,7 @@ __device__ __forceinline__ void write_block_header(Lane &L, uint8_t *p)
   L.w1 &= mask;
   L.w2 &= mask;
   L.w3 &= mask;
-  store_be16(p, (((uint32_t)L.idx << 4) & 0xFFFFu) | ((uint32_t)shift & 0xFu));
+  store_be16(p, ((((uint32_t)(L.idxb - kIdxBias)) << 4) & 0xFFFFu) | ((uint32_t)shift & 0xFu));
   store_be16(p + 2, (uint32_t)(L.w0 >> shift));
   store_be16(p + 4, (uint32_t)L.h0);
   store_be16(p + 6, (uint32_t)(L.w1 >> shift));
@@ -375,32 +588,75 @@ __device__ __forceinline__ void write_block_header(Lane &L, uint8_t *p)
   store_be16(p + 16, (uint32_t)L.h3);
 }
 
+/* Write the packed codes of one 16-sample chunk.  w[]: big-endian code words of this lane's
+ * channel.  up: first byte of the chunk's first unit of channel 0.  For stereo the two lanes of
+ * a pair trade one word through DPP and each writes half of the interleaved bytes. */
+template <int BITS, int CHF>
+__device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w, uint32_t c)
+{
+  if (CHF == 1) {
+    if (BITS == 4) {
+      u32x2 v;
+      v.x = perm(0, w[0], 0x00010203);
+      v.y = perm(0, w[1], 0x00010203);
+      reinterpret_cast<U32x2 *>(up)->v = v;
+    } else if (BITS == 2) {
+      reinterpret_cast<U32 *>(up)->v = perm(0, w[0], 0x00010203);
+    } else { /* a0 a1 a2 a3 | a4 a5 : w0 = 0 a0 a1 a2, w1 = 0 a3 a4 a5 */
+      reinterpret_cast<U32 *>(up)->v = perm(w[1], w[0], 0x06000102);
+      reinterpret_cast<U16 *>(up + 4)->v = (uint16_t)perm(0, w[1], 0x0c0c0001);
+    }
+  } else { /* stereo */
+    if (BITS == 2) { /* out: a0 b0 a1 b1 | a2 b2 a3 b3 ; lane c writes dword c */
+      const uint32_t other = pair_swap(w[0]);
+      const uint32_t A = c ? other : w[0], B = c ? w[0] : other; /* A = channel 0 word, B = channel 1 word */
+      reinterpret_cast<U32 *>(up + 4 * c)->v = perm(A, B, c ? 0x00040105u : 0x02060307u);
+    } else {
+      /* lane 0 writes the first half (needs word 0 of both channels), lane 1 the second half */
+      const uint32_t send = c ? w[0] : w[1], keep = c ? w[1] : w[0];
+      const uint32_t recv = pair_swap(send);
+      const uint32_t A = c ? recv : keep, B = c ? keep : recv;
+      if (BITS == 4) { /* a0 b0 a1 b1 | a2 b2 a3 b3 from A = a0 a1 a2 a3, B = b0 b1 b2 b3 (big-endian words) */
+        u32x2 v;
+        v.x = perm(A, B, 0x02060307);
+        v.y = perm(A, B, 0x00040105);
+        reinterpret_cast<U32x2 *>(up + 8 * c)->v = v;
+      } else { /* a0 a1 a2 b0 | b1 b2 from A = 0 a0 a1 a2, B = 0 b0 b1 b2 */
+        reinterpret_cast<U32 *>(up + 6 * c)->v = perm(A, B, 0x02040506);
+        reinterpret_cast<U16 *>(up + 6 * c + 4)->v = (uint16_t)perm(A, B, 0x0c0c0001);
+      }
+    }
+  }
+}
+
 /*
  * Stream-parallel encode (reference src/aad_encoder.c:814-891 with EncodeBlock :565-727 and the
  * optional trial search :470-562 inlined).  lane = (stream, channel).
  */
-template <int BITS>
-__global__ void __launch_bounds__(64) encode_streams_kernel(EncodeArgs a)
+template <int BITS, int CHF, bool MS>
+__global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
-  __shared__ StepEntry tab[AAD_STEP_TABLE_LEN];
-  stage_step_table(tab);
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  stage_tables<BITS>(lds);
 
-  const uint32_t ch = a.channels;
+  const uint32_t ch = CHF ? CHF : a.channels;
   const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (lane >= (uint64_t)a.num_streams * ch) return;
+  if (lane >= (uint64_t)a.num_streams * ch) return; /* whole stereo pairs leave together */
   const uint32_t s = (uint32_t)(lane / ch), c = (uint32_t)(lane % ch);
   const StreamDesc sd = a.streams[s];
-  const SampleSource src = {a.pcm + sd.pcm_offset, ch, c, a.mid_side};
+  const SampleSource<MS> src = {a.pcm + sd.pcm_offset, ch, c};
   uint8_t *out = a.data + sd.data_offset;
   const uint32_t total = sd.num_samples, spb = a.samples_per_block;
 
-  Lane L = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Lane L = {0, 0, 0, 0, 0, 0, 0, 0, kIdxBias};
+  int32_t last_qd = 0;
   if (a.state) {
     const LaneStateRecord r = a.state[lane];
     L = {r.weight[0], r.weight[1], r.weight[2], r.weight[3],
-         r.history[0], r.history[1], r.history[2], r.history[3], r.stepsize_index};
+         r.history[0], r.history[1], r.history[2], r.history[3],
+         min(max(r.stepsize_index, 0), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias};
+    last_qd = r.quantize_error;
   }
-  int32_t last_qd = a.state ? a.state[lane].quantize_error : 0;
 
   if (c == 0) { /* file header - reference src/aad_encoder.c:190-214 */
     for (int i = 0; i < kFileHeaderBytes; i++) out[i] = a.header_template[i];
@@ -415,16 +671,60 @@ __global__ void __launch_bounds__(64) encode_streams_kernel(EncodeArgs a)
   uint64_t block_off = kFileHeaderBytes;
   for (uint64_t first = 0; first < total; first += spb, block_off += a.block_size) {
     const uint32_t n = total - first < spb ? (uint32_t)(total - first) : spb;
-    if (a.trials) search_best_lane<BITS>(L, src, first, n, spb, a.trials, tab);
+    if (a.trials) search_best_lane<BITS>(L, src, first, n, spb, a.trials, lds);
     seed_history(L, src, first, n);
     write_block_header(L, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh);
-    uint8_t *up = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch + (uint64_t)c * UB;
-    for (uint32_t i = kTaps; i < n; i += US, up += unit_stride) {
+    uint8_t *body = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch;
+    const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
+    uint32_t done = 0;
+
+    {
+      /* full chunks: 16 real samples each, wide loads and stores */
+      using CS = ChunkSamples<CHF, MS>;
+      const uint32_t full = coded / kChunk;
+      const int16_t *xp = src.x + (first + kTaps) * ch;
+      constexpr uint32_t kOutStride = Pack<BITS>::kChunkBytes;
+      CS next;
+      if (full) next.load(xp, ch, c);
+      for (uint32_t k = 0; k < full; k++) {
+        const CS cur = next;
+        xp += (uint64_t)kChunk * ch;
+        if (k + 1 < full) next.load(xp, ch, c);
+        uint32_t w[2] = {0, 0};
+        auto steps = [&](auto fast) {
+          static_for<0, kChunk>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const uint32_t code = encode_step<BITS, decltype(fast)::value>(L, cur.get(j, c), lds, last_qd);
+            uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
+            acc = (acc << BITS) | code;
+          });
+        };
+        if (weights_fit_24(L)) steps(std::true_type{}); else steps(std::false_type{});
+        if (CHF != 0) {
+          store_chunk_codes<BITS, (CHF ? CHF : 1)>(body + (uint64_t)k * kOutStride * ch, w, c);
+        } else { /* any channel count: this lane's unit bytes one by one */
+          uint8_t *up = body + (uint64_t)k * kOutStride * ch + (uint64_t)c * UB;
+#pragma unroll
+          for (int u = 0; u < kChunk / US; u++) {
+            const int per_word = Pack<BITS>::kCodesPerWord / US; /* units per code word */
+            const uint32_t word = w[u / per_word];
+            const uint32_t unit = word >> (8 * UB * (per_word - 1 - (u % per_word)));
+#pragma unroll
+            for (int q = 0; q < UB; q++) up[(uint64_t)u * unit_stride + q] = (uint8_t)(unit >> (8 * (UB - 1 - q)));
+          }
+        }
+      }
+      done = full * kChunk;
+    }
+
+    /* tail units: samples past n are zero padding - reference :592-593 */
+    uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
+    for (uint32_t i = done; i < coded; i += US, up += unit_stride) {
       uint32_t acc = 0;
 #pragma unroll
-      for (int k = 0; k < US; k++) { /* samples past n are zero padding - reference :592-593 */
-        const int32_t x = i + k < n ? src.at(first + i + k) : 0;
-        acc = (acc << BITS) | encode_step<BITS>(L, x, tab, last_qd);
+      for (int k = 0; k < US; k++) {
+        const int32_t x = i + k < coded ? src.at(first + kTaps + i + k) : 0;
+        acc = (acc << BITS) | encode_step<BITS, false>(L, x, lds, last_qd);
       }
 #pragma unroll
       for (int k = 0; k < UB; k++) up[k] = (uint8_t)(acc >> (8 * (UB - 1 - k)));
@@ -435,7 +735,7 @@ __global__ void __launch_bounds__(64) encode_streams_kernel(EncodeArgs a)
     LaneStateRecord r;
     r.weight[0] = L.w0; r.weight[1] = L.w1; r.weight[2] = L.w2; r.weight[3] = L.w3;
     r.history[0] = L.h0; r.history[1] = L.h1; r.history[2] = L.h2; r.history[3] = L.h3;
-    r.stepsize_index = L.idx;
+    r.stepsize_index = L.idxb - kIdxBias;
     r.quantize_error = last_qd;
     a.state[lane] = r;
   }

@@ -42,8 +42,37 @@ struct AADHipDecodePlan {
 
 namespace {
 
-constexpr unsigned kWorkgroup = 64; /* one wave per workgroup: lanes are scarce in every BASELINE
-                                       config, so spread waves over as many SIMDs as possible */
+/* Lanes are scarce in every BASELINE config: while the batch has fewer
+ * waves than the chip has SIMDs (256 CUs x 4) each wave gets a workgroup of its own so the
+ * dispatcher spreads them over as many SIMDs as possible; big batches use 256-thread
+ * workgroups so four waves share one LDS copy of the tables. */
+unsigned pick_workgroup(uint64_t lanes) { return lanes <= 64ull * 1024ull ? 64u : 256u; }
+
+template <int BITS>
+void launch_encode(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
+{
+  if (a.channels == 1)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false>), grid, block, 0, stream, a);
+  else if (a.channels == 2 && a.mid_side)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true>), grid, block, 0, stream, a);
+  else if (a.channels == 2)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false>), grid, block, 0, stream, a);
+}
+
+template <int BITS>
+void launch_decode(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
+{
+  if (a.channels == 1)
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 1, false>), grid, block, 0, stream, a);
+  else if (a.channels == 2 && a.mid_side)
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true>), grid, block, 0, stream, a);
+  else if (a.channels == 2)
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false>), grid, block, 0, stream, a);
+}
 
 bool hip_ok(AADHipContext *ctx, hipError_t e, const char *what)
 {
@@ -219,11 +248,12 @@ AADApiResult AADHip_EncodePlanRun(struct AADHipEncodePlan *plan, const int16_t *
   a.data = device_data;
   a.state = reinterpret_cast<aad::LaneStateRecord *>(device_state);
   const uint64_t lanes = (uint64_t)a.num_streams * a.channels;
-  const dim3 grid((unsigned)((lanes + kWorkgroup - 1) / kWorkgroup)), block(kWorkgroup);
+  const unsigned wg = pick_workgroup(lanes);
+  const dim3 grid((unsigned)((lanes + wg - 1) / wg)), block(wg);
   switch (a.bits) {
-    case 4: hipLaunchKernelGGL(aad::encode_streams_kernel<4>, grid, block, 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL(aad::encode_streams_kernel<3>, grid, block, 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL(aad::encode_streams_kernel<2>, grid, block, 0, ctx->stream, a); break;
+    case 4: launch_encode<4>(a, grid, block, ctx->stream); break;
+    case 3: launch_encode<3>(a, grid, block, ctx->stream); break;
+    case 2: launch_encode<2>(a, grid, block, ctx->stream); break;
     default: return AAD_APIRESULT_INVALID_FORMAT;
   }
   return hip_ok(ctx, hipGetLastError(), "encode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
@@ -313,11 +343,12 @@ AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *
   a.data = device_data;
   a.pcm = device_pcm;
   const uint64_t lanes = a.total_blocks * a.channels;
-  const dim3 grid((unsigned)((lanes + kWorkgroup - 1) / kWorkgroup)), block(kWorkgroup);
+  const unsigned wg = pick_workgroup(lanes);
+  const dim3 grid((unsigned)((lanes + wg - 1) / wg)), block(wg);
   switch (a.bits) {
-    case 4: hipLaunchKernelGGL(aad::decode_blocks_kernel<4>, grid, block, 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL(aad::decode_blocks_kernel<3>, grid, block, 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL(aad::decode_blocks_kernel<2>, grid, block, 0, ctx->stream, a); break;
+    case 4: launch_decode<4>(a, grid, block, ctx->stream); break;
+    case 3: launch_decode<3>(a, grid, block, ctx->stream); break;
+    case 2: launch_decode<2>(a, grid, block, ctx->stream); break;
     default: return AAD_APIRESULT_INVALID_FORMAT;
   }
   return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;

@@ -33,14 +33,30 @@ class Engine:
         self.lib = lib or load_library()
         self.device = int(device)
         torch.cuda.set_device(self.device)
+        # The C context launches on an explicit stream.  Use torch's current stream when it is a
+        # real one; the legacy null stream cannot be named through a pointer, so in that case the
+        # engine owns a torch side stream and orders it against the caller's stream around every
+        # run (see _enter/_exit).  `with torch.cuda.stream(engine.stream):` avoids even that.
         if stream == "torch":
-            stream_ptr = torch.cuda.current_stream(self.device).cuda_stream
+            cur = torch.cuda.current_stream(self.device)
+            self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(self.device)
         elif stream is None:
-            stream_ptr = None
+            self.stream = torch.cuda.Stream(self.device)
         else:
-            stream_ptr = int(stream)
+            self.stream = stream  # a torch.cuda.Stream
         self._ctx = C.c_void_p()
-        _check("AADHip_ContextCreate", self.lib.AADHip_ContextCreate(self.device, stream_ptr, C.byref(self._ctx)))
+        _check("AADHip_ContextCreate",
+               self.lib.AADHip_ContextCreate(self.device, self.stream.cuda_stream, C.byref(self._ctx)))
+
+    def _enter(self):
+        cur = self.torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self.stream.wait_stream(cur)
+        return cur
+
+    def _exit(self, cur):
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)
 
     def close(self):
         if self._ctx:
@@ -168,8 +184,10 @@ class EncodePlan:
     def run(self, pcm, data, state=None):
         """pcm: int16 cuda tensor, data: uint8 cuda tensor, state: int32 cuda tensor [lanes, 10] or None"""
         sp = state.data_ptr() if state is not None else None
+        cur = self.engine._enter()
         _check("AADHip_EncodePlanRun",
                self.engine.lib.AADHip_EncodePlanRun(self.handle, pcm.data_ptr(), data.data_ptr(), sp))
+        self.engine._exit(cur)
 
     def close(self):
         if self.handle:
@@ -188,8 +206,10 @@ class DecodePlan:
         self.engine, self.handle, self.header, self.descs = engine, handle, header, descs
 
     def run(self, data, pcm):
+        cur = self.engine._enter()
         _check("AADHip_DecodePlanRun",
                self.engine.lib.AADHip_DecodePlanRun(self.handle, data.data_ptr(), pcm.data_ptr()))
+        self.engine._exit(cur)
 
     def close(self):
         if self.handle:

@@ -192,6 +192,9 @@ def main():
     pcm_np = synth_pcm(args.streams, samples, ch, seed=1234, first_stream=rank * args.streams)
     pcm = torch.from_numpy(pcm_np).cuda()
 
+    torch.cuda.synchronize()
+    # everything timed below is launched on the engine's stream, and the HIP events are recorded on it
+    torch.cuda.set_stream(engine.stream)
     m = measure(engine, torch, dist, pcm, param, args.steps, args.warmup, world)
     hd = m["header"]
     n_step = args.streams * samples * ch  # channel-samples per direction per rank
