@@ -234,6 +234,67 @@ __device__ __forceinline__ int32_t decode_step(Lane &L, uint32_t word, const cha
   return y;
 }
 
+/*
+ * Sixteen encoder steps, software-pipelined by hand.  The encoder's recurrence runs through two
+ * dependent LDS lookups per sample (code -> index delta -> step record of the NEXT sample), ~55
+ * cycles each for a lone wave.  The compiler's schedule waits for both right after issuing
+ * them; here every sample is cut into four regions separated by scheduling barriers so that
+ * each lookup has ~14 independent instructions (~60 cycles) issued behind it:
+ *   A  quantise with the step record fetched during the previous sample; start the delta lookup
+ *   B  dequantise, reconstruct, LMS taps 0-1, pack the code            (hides the delta lookup)
+ *   C  new step index; start the lookup of the next sample's step record
+ *   D  LMS taps 2-3, history shift, predict + difference of the NEXT sample (hides the record lookup)
+ * Same arithmetic as encode_step, instruction for instruction.
+ */
+template <int BITS, bool FAST24>
+__device__ __forceinline__ void encode_chunk16(Lane &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out)
+{
+  /* 12 of the record's 16 bytes: a b128 read would also tie up a 4th register until it lands */
+  u32x3 e = *reinterpret_cast<const u32x3 *>(lds + (L.idxb & 0xFF0));
+  int32_t p = predict<FAST24>(L);
+  int32_t d = x[0] - p;
+  int32_t m = d >> 31;
+  float f = (float)d;
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    /* A */
+    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)),
+                             Pack<BITS>::kMagMax);
+    const uint32_t m21 = (mag << 1) | 1u;
+    const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDeltaOff - 1) + m21);
+    __builtin_amdgcn_sched_barrier(0);
+    /* B */
+    const int32_t q = (int32_t)(__umul24(e.x, m21) >> (BITS - 1));
+    const int32_t qd = (q ^ m) - m;
+    const int32_t y = clip16(qd + p);
+    L.w0 += mad_i24(qd, L.h0, 16384) >> 18;
+    L.w1 += mad_i24(qd, L.h1, 16384) >> 18;
+    uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
+    acc = (acc << BITS) | mag | ((uint32_t)m & Pack<BITS>::kSign);
+    __builtin_amdgcn_sched_barrier(0);
+    /* C */
+    L.idxb = min(max(L.idxb + delta, kIdxMin), kIdxMax);
+    if (j + 1 < kChunk) e = *reinterpret_cast<const u32x3 *>(lds + (L.idxb & 0xFF0));
+    __builtin_amdgcn_sched_barrier(0);
+    /* D */
+    L.w2 += mad_i24(qd, L.h2, 16384) >> 18;
+    L.w3 += mad_i24(qd, L.h3, 16384) >> 18;
+    L.h3 = L.h2;
+    L.h2 = L.h1;
+    L.h1 = L.h0;
+    L.h0 = y;
+    if (j + 1 < kChunk) {
+      p = predict<FAST24>(L);
+      d = x[j + 1] - p;
+      m = d >> 31;
+      f = (float)d;
+    } else {
+      qd_out = qd;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 /* ---- per-lane byte shuffles ------------------------------------------------------------- */
 
 /* v_perm_b32: selector bytes 0-3 pick from `lo`, 4-7 from `hi`, 0x0c yields 0x00 */
@@ -280,41 +341,104 @@ __device__ __forceinline__ uint32_t load_be16(const uint8_t *p) { return ((uint3
  * and turn them big-endian).  `p` points at the first byte of the chunk's first unit of channel 0. */
 template <int BITS, int CHF>
 struct ChunkCodes {
-  uint32_t w[2];
+  uint32_t r[4]; /* raw dwords as loaded */
   /* bytes the wide load touches, measured from p */
   static constexpr int kLoadBytes = CHF == 1 ? (BITS == 2 ? 4 : 8) : (BITS == 4 ? 16 : (BITS == 3 ? 12 : 8));
-  __device__ __forceinline__ void load(const uint8_t *p, uint32_t c)
+  static constexpr int kRaw = kLoadBytes / 4;
+  __device__ __forceinline__ void load(const uint8_t *p)
+  {
+    if (kRaw == 1) {
+      r[0] = reinterpret_cast<const U32 *>(p)->v;
+    } else if (kRaw == 2) {
+      const u32x2 d = reinterpret_cast<const U32x2 *>(p)->v;
+      r[0] = d.x; r[1] = d.y;
+    } else if (kRaw == 3) {
+      const u32x3 d = reinterpret_cast<const U32x3 *>(p)->v;
+      r[0] = d.x; r[1] = d.y; r[2] = d.z;
+    } else {
+      const u32x4 d = reinterpret_cast<const U32x4 *>(p)->v;
+      r[0] = d.x; r[1] = d.y; r[2] = d.z; r[3] = d.w;
+    }
+  }
+  /* Claim the loaded registers without emitting an instruction: the compiler has to place the
+   * s_waitcnt for the prefetch HERE (a whole chunk of arithmetic after it was issued) instead of
+   * at the top of the next iteration behind a burst of fresh stores - gfx950 has one vmcnt for
+   * loads and stores, so a wait placed after the stores would also wait for every one of them. */
+  __device__ __forceinline__ void touch()
+  {
+    if (kRaw == 1) asm volatile("" : "+v"(r[0]) :: "memory");
+    if (kRaw == 2) asm volatile("" : "+v"(r[0]), "+v"(r[1]) :: "memory");
+    if (kRaw == 3) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) :: "memory");
+    if (kRaw == 4) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+  }
+  /* big-endian code words of channel c */
+  __device__ __forceinline__ void unpack(uint32_t c, uint32_t *w) const
   {
     if (CHF == 1) {
       if (BITS == 2) {
-        w[0] = perm(0, reinterpret_cast<const U32 *>(p)->v, 0x00010203);
-      } else {
-        const u32x2 d = reinterpret_cast<const U32x2 *>(p)->v;
-        if (BITS == 4) {
-          w[0] = perm(0, d.x, 0x00010203);
-          w[1] = perm(0, d.y, 0x00010203);
-        } else { /* two 3-byte units */
-          w[0] = perm(d.y, d.x, 0x0c000102);
-          w[1] = perm(d.y, d.x, 0x0c030405);
-        }
+        w[0] = perm(0, r[0], 0x00010203);
+      } else if (BITS == 4) {
+        w[0] = perm(0, r[0], 0x00010203);
+        w[1] = perm(0, r[1], 0x00010203);
+      } else { /* two 3-byte units */
+        w[0] = perm(r[1], r[0], 0x0c000102);
+        w[1] = perm(r[1], r[0], 0x0c030405);
       }
     } else {
       if (BITS == 4) { /* L R L R ...: own bytes c, c+2 of every dword */
-        const u32x4 d = reinterpret_cast<const U32x4 *>(p)->v;
         const uint32_t sel = 0x00020406u + c * 0x01010101u;
-        w[0] = perm(d.y, d.x, sel);
-        w[1] = perm(d.w, d.z, sel);
+        w[0] = perm(r[1], r[0], sel);
+        w[1] = perm(r[3], r[2], sel);
       } else if (BITS == 2) {
-        const u32x2 d = reinterpret_cast<const U32x2 *>(p)->v;
-        w[0] = perm(d.y, d.x, 0x00020406u + c * 0x01010101u);
+        w[0] = perm(r[1], r[0], 0x00020406u + c * 0x01010101u);
       } else { /* L3 R3 L3 R3 */
-        const u32x3 d = reinterpret_cast<const U32x3 *>(p)->v;
-        w[0] = perm(d.y, d.x, c ? 0x0c030405u : 0x0c000102u);
-        w[1] = perm(d.z, d.y, c ? 0x0c050607u : 0x0c020304u);
+        w[0] = perm(r[1], r[0], c ? 0x0c030405u : 0x0c000102u);
+        w[1] = perm(r[2], r[1], c ? 0x0c050607u : 0x0c020304u);
       }
     }
   }
 };
+
+/* Write 16 decoded samples of channel c (y[], int16 range) as interleaved PCM.  Mono: two 16-byte
+ * stores.  Stereo: the two lanes of a pair trade half of their packed samples through DPP and
+ * each writes 2 x 16 contiguous bytes of L/R frames.  A vector-memory instruction costs a lone
+ * wave ~17 cycles to issue whatever its width, so few wide stores beat one short per sample. */
+template <int CHF>
+__device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *y, uint32_t c, uint32_t ch)
+{
+  if (CHF == 1) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      u32x4 v;
+      v.x = perm((uint32_t)y[8 * h + 1], (uint32_t)y[8 * h + 0], 0x05040100);
+      v.y = perm((uint32_t)y[8 * h + 3], (uint32_t)y[8 * h + 2], 0x05040100);
+      v.z = perm((uint32_t)y[8 * h + 5], (uint32_t)y[8 * h + 4], 0x05040100);
+      v.w = perm((uint32_t)y[8 * h + 7], (uint32_t)y[8 * h + 6], 0x05040100);
+      reinterpret_cast<U32x4 *>(frame0 + 8 * h)->v = v;
+    }
+  } else if (CHF == 2) {
+    /* per 8 samples: lane 0 writes frames 0-3 (own samples 0-3 + partner's), lane 1 frames 4-7 */
+    const uint32_t sel_lo = c ? 0x05040100u : 0x01000504u, sel_hi = c ? 0x07060302u : 0x03020706u;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint32_t p0 = perm((uint32_t)y[8 * h + 1], (uint32_t)y[8 * h + 0], 0x05040100);
+      const uint32_t p1 = perm((uint32_t)y[8 * h + 3], (uint32_t)y[8 * h + 2], 0x05040100);
+      const uint32_t p2 = perm((uint32_t)y[8 * h + 5], (uint32_t)y[8 * h + 4], 0x05040100);
+      const uint32_t p3 = perm((uint32_t)y[8 * h + 7], (uint32_t)y[8 * h + 6], 0x05040100);
+      const uint32_t ra = pair_swap(c ? p0 : p2), rb = pair_swap(c ? p1 : p3);
+      const uint32_t ka = c ? p2 : p0, kb = c ? p3 : p1;
+      u32x4 v;
+      v.x = perm(ka, ra, sel_lo);
+      v.y = perm(ka, ra, sel_hi);
+      v.z = perm(kb, rb, sel_lo);
+      v.w = perm(kb, rb, sel_hi);
+      reinterpret_cast<U32x4 *>(frame0 + 16 * h + 8 * c)->v = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kChunk; j++) frame0[(uint32_t)j * ch + c] = (int16_t)y[j];
+  }
+}
 
 /*
  * Block-parallel decode (reference src/aad_decoder.c:321-475, looped by :514-534).
@@ -401,22 +525,30 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       full = full < fit ? full : fit;
     }
     const uint8_t *cp = src + body;
-    int16_t *op = dst + (uint64_t)kTaps * ch;
+    int16_t *op = a.pcm + sd.pcm_offset + (first + kTaps) * ch; /* frame of this chunk's first sample, channel 0 */
     CC next;
-    if (full) next.load(cp, c);
+    next.r[0] = next.r[1] = next.r[2] = next.r[3] = 0;
+    if (full) next.load(cp);
+    next.touch();
     for (uint32_t k = 0; k < full; k++) {
-      const CC cur = next;
-      cp += kStride;
-      if (k + 1 < full) next.load(cp, c); /* prefetch the next chunk under this one's arithmetic */
-      auto body = [&](auto fast) {
+      uint32_t w[2] = {0, 0};
+      next.unpack(c, w);
+      /* prefetch the next chunk (the last iteration re-reads its own: an unconditional load lands
+       * straight in `next`'s registers, a conditional one would be copied - and waited for - at once);
+       * it is consumed (touch) only after this chunk's arithmetic */
+      if (k + 1 < full) cp += kStride;
+      next.load(cp);
+      int32_t y[kChunk];
+      auto body16 = [&](auto fast) {
         static_for<0, kChunk>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           constexpr int cpw = Pack<BITS>::kCodesPerWord;
-          const int32_t y = decode_step<BITS, Pack<BITS>::pos(j % cpw), decltype(fast)::value>(L, cur.w[j / cpw], lds);
-          op[(uint32_t)j * ch] = (int16_t)finish(y);
+          y[j] = finish(decode_step<BITS, Pack<BITS>::pos(j % cpw), decltype(fast)::value>(L, w[j / cpw], lds));
         });
       };
-      if (weights_fit_24(L)) body(std::true_type{}); else body(std::false_type{});
+      if (weights_fit_24(L)) body16(std::true_type{}); else body16(std::false_type{});
+      next.touch();
+      store_chunk_pcm<CHF>(op, y, c, ch);
       op += (uint64_t)kChunk * ch;
     }
     done = full * kChunk;
@@ -496,6 +628,15 @@ struct ChunkSamples {
 #pragma unroll
       for (int k = 0; k < 16; k++) d[k] = (uint32_t)(int32_t)x[(uint32_t)k * ch + c];
     }
+  }
+  /* see ChunkCodes::touch */
+  __device__ __forceinline__ void touch()
+  {
+    constexpr int n = CHF == 1 ? 8 : 16;
+    asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]) :: "memory");
+    if (n == 16)
+      asm volatile("" : "+v"(d[n - 8]), "+v"(d[n - 7]), "+v"(d[n - 6]), "+v"(d[n - 5]), "+v"(d[n - 4]), "+v"(d[n - 3]),
+                        "+v"(d[n - 2]), "+v"(d[n - 1]) :: "memory");
   }
   __device__ __forceinline__ int32_t get(int j, uint32_t c) const
   {
@@ -685,21 +826,20 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
       const int16_t *xp = src.x + (first + kTaps) * ch;
       constexpr uint32_t kOutStride = Pack<BITS>::kChunkBytes;
       CS next;
+      for (auto &v : next.d) v = 0;
       if (full) next.load(xp, ch, c);
+      next.touch();
       for (uint32_t k = 0; k < full; k++) {
-        const CS cur = next;
-        xp += (uint64_t)kChunk * ch;
-        if (k + 1 < full) next.load(xp, ch, c);
+        int32_t x[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) x[j] = next.get(j, c);
+        /* unconditional prefetch (the last iteration re-reads its own chunk), see the decoder */
+        if (k + 1 < full) xp += (uint64_t)kChunk * ch;
+        next.load(xp, ch, c);
         uint32_t w[2] = {0, 0};
-        auto steps = [&](auto fast) {
-          static_for<0, kChunk>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const uint32_t code = encode_step<BITS, decltype(fast)::value>(L, cur.get(j, c), lds, last_qd);
-            uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
-            acc = (acc << BITS) | code;
-          });
-        };
-        if (weights_fit_24(L)) steps(std::true_type{}); else steps(std::false_type{});
+        if (weights_fit_24(L)) encode_chunk16<BITS, true>(L, x, lds, w, last_qd);
+        else encode_chunk16<BITS, false>(L, x, lds, w, last_qd);
+        next.touch();
         if (CHF != 0) {
           store_chunk_codes<BITS, (CHF ? CHF : 1)>(body + (uint64_t)k * kOutStride * ch, w, c);
         } else { /* any channel count: this lane's unit bytes one by one */
