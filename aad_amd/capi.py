@@ -57,7 +57,7 @@ LANE_STATE_DTYPE = np.dtype([("weight", "<i4", (4,)), ("history", "<i4", (4,)),
                              ("stepsize_index", "<i4"), ("quantize_error", "<i4")])
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_PKG_DIR, "libaad_hip.so")
+LIBRARY_PATH = os.environ.get("AAD_HIP_LIBRARY", os.path.join(_PKG_DIR, "libaad_hip.so"))
 
 LEGACY_SYMBOLS = [
     "AADEncoder_CalculateBlockSize", "AADEncoder_EncodeHeader", "AADEncoder_CalculateWorkSize",

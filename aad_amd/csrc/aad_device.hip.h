@@ -13,16 +13,17 @@
  * therefore the NUMBER of instructions on the per-sample path, not their kind:
  *   - the whole per-channel state (4 weights, 4 history samples, step index) lives in VGPRs,
  *     history rotation is free because samples are processed in unrolled chunks of 16;
- *   - the step table sits in LDS as 16-byte records {step, fl32(0.5/step), fl32(2^(b-1)*0.5/step)}
- *     addressed by (index & 0xFF0): one v_and + one ds_read_b128;
+ *   - step size, fl32(0.5/step) and fl32(2^(b-1)*0.5/step) sit in LDS as dense dword arrays
+ *     (bank-conflict free), fetched one sample ahead in hand-pipelined 16-sample chunks;
  *   - the quantiser's integer division is  min(trunc(fma(|d|, hs, hr)), magmax)  - convert, fma
  *     with |.| source modifier, convert, min - proved equal to the reference's division for
  *     every reachable operand (tests/test_quantiser_equiv.py);
- *   - the step-index delta is one ds_read_i16 addressed by the odd number 2*mag+1 that the
- *     dequantiser needs anyway;
- *   - predict is a v_mad_i32_i24 chain while the weights provably fit 24 bits (checked once per
- *     chunk; real audio stays below 2^17) with an exact 32-bit-multiply twin for any weights;
- *     the LMS products always use v_mad_i32_i24 (|qd| <= 61438, |h| <= 32768: exact);
+ *   - encoder: the step-index delta is one ds_read_i16 addressed by the odd number 2*mag+1 that
+ *     the dequantiser needs anyway; decoder: one 12-byte record per code gives the signed
+ *     multiplier, the rounding bias and the delta, so dequantising is a mad + a shift;
+ *   - predict uses full 32-bit multiplies (exact int32 wraparound for ANY weights; v_mul_lo_u32
+ *     issues as fast as the 24-bit forms on gfx950), the LMS products v_mad_i32_i24
+ *     (|qd| <= 61438, |h| <= 32768: exact);
  *   - code bytes are read/written in wide unaligned accesses per 16-sample chunk; the stereo
  *     L/R byte interleave is one DPP lane swap plus v_perm_b32 byte permutes.
  * There is no contraction anywhere, hence no MFMA.
@@ -45,14 +46,27 @@ constexpr int kBlockHeaderBytesPerCh = 18;
 constexpr int kFileHeaderBytes = 31;
 constexpr int kChunk = 16; /* samples per unrolled chunk: a multiple of every pack unit (2, 8, 4) and of the tap count */
 
-/* the step index is kept biased by +8 so that (index & 0xFF0) is the byte offset of its table record */
+/*
+ * LDS image (one per workgroup, ~3.3 KB).  Dense dword arrays so that a lookup is bank-conflict
+ * free unless two lanes hit different entries 32 apart:
+ *   step[256]   uint32   step size
+ *   hr[256]     float    fl32(0.5 / step)
+ *   hs[256]     float    2^(BITS-1) * hr
+ *   code[16]    {int32 sm21, int32 bias, int32 delta, -}   decoder: everything a code implies
+ *   delta[8]    int16    encoder: index delta by magnitude
+ * (A first layout used one 16-byte record per step: only 8 bank groups, SQ_LDS_BANK_CONFLICT was
+ * half of all LDS cycles and lookups on the recurrence's critical path took ~100 cycles.)
+ * The Q4 step index is kept biased by +8 (idxb), so its table slot is idxb >> 4.
+ */
 constexpr int kIdxBias = 8;
 constexpr int kIdxMin = kIdxBias, kIdxMax = AAD_STEP_INDEX_MAX + kIdxBias;
+constexpr int kLdsStepOff = 0, kLdsHrOff = 1024, kLdsHsOff = 2048;
+constexpr int kLdsCodeOff = 3072;
+constexpr int kLdsDeltaOff = kLdsCodeOff + 16 * 16;
+constexpr int kLdsBytes = kLdsDeltaOff + 16;
 
-/* LDS image: 256 x 16-byte step records, then the index deltas of this bit width as int16 */
-constexpr int kLdsStepBytes = AAD_STEP_TABLE_LEN * 16;
-constexpr int kLdsDeltaOff = kLdsStepBytes;
-constexpr int kLdsBytes = kLdsStepBytes + 16;
+/* byte offset of the step index's slot in the dword arrays */
+__device__ __forceinline__ uint32_t slot_addr(int32_t idxb) { return ((uint32_t)idxb >> 2) & 0x3FCu; }
 
 __constant__ uint16_t c_step_table[AAD_STEP_TABLE_LEN] = {AAD_STEP_TABLE_VALUES};
 __constant__ uint32_t c_half_recip_bits[AAD_STEP_TABLE_LEN] = {AAD_HALF_RECIP_BITS};
@@ -118,55 +132,55 @@ struct Pack {
 template <int BITS>
 __device__ __forceinline__ void stage_tables(char *lds)
 {
+  constexpr int kShift = BITS - 1;
   for (int i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) {
     const float hr = __uint_as_float(c_half_recip_bits[i]);
+    reinterpret_cast<uint32_t *>(lds + kLdsStepOff)[i] = c_step_table[i];
+    reinterpret_cast<float *>(lds + kLdsHrOff)[i] = hr;
+    reinterpret_cast<float *>(lds + kLdsHsOff)[i] = hr * (float)(1 << kShift); /* exact power-of-two scaling */
+  }
+  const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
+  if (threadIdx.x < (1 << BITS)) {
+    /* code -> {signed 2*mag+1, rounding bias, index delta}:
+     * qd = (step * sm21 + bias) >> (BITS-1) equals the reference's sign ? -q : q, q = (step * m21) >> (BITS-1) */
+    const int code = threadIdx.x, mag = code & ((1 << kShift) - 1), neg = code >> kShift;
     u32x4 e;
-    e.x = c_step_table[i];
-    e.y = __float_as_uint(hr);
-    e.z = __float_as_uint(hr * (float)(1 << (BITS - 1))); /* exact power-of-two scaling */
+    e.x = (uint32_t)(neg ? -(2 * mag + 1) : (2 * mag + 1));
+    e.y = neg ? (1u << kShift) - 1u : 0u;
+    e.z = (uint32_t)(int32_t)dt[mag];
     e.w = 0;
-    *reinterpret_cast<u32x4 *>(lds + i * 16) = e;
+    *reinterpret_cast<u32x4 *>(lds + kLdsCodeOff + (code << 4)) = e;
   }
-  if (threadIdx.x < 8) {
-    int16_t d = 0;
-    if (BITS == 4) d = c_delta4[threadIdx.x & 7];
-    if (BITS == 3) d = c_delta3[threadIdx.x & 3];
-    if (BITS == 2) d = c_delta2[threadIdx.x & 1];
-    reinterpret_cast<int16_t *>(lds + kLdsDeltaOff)[threadIdx.x] = d;
-  }
+  if (threadIdx.x < 8) reinterpret_cast<int16_t *>(lds + kLdsDeltaOff)[threadIdx.x] = dt[threadIdx.x & ((1 << kShift) - 1)];
   __syncthreads();
 }
 
 __device__ __forceinline__ int32_t clip16(int32_t v) { return min(max(v, -32768), 32767); }
+
+/* Pin a value's computation between the surrounding scheduling barriers.  sched_barrier only
+ * orders instructions with side effects; pure arithmetic is free to sink past it (it did: the
+ * compiler ran all sixteen table lookups first and the whole LMS chain afterwards).  A volatile
+ * empty asm that "modifies" the value is ordered against the barriers and emits nothing. */
+__device__ __forceinline__ void pin(int32_t &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(uint32_t &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ int32_t clamp_idx(int32_t v) { return min(max(v, kIdxMin), kIdxMax); }
 
 /* a*b + c on the 24-bit multiplier (v_mad_i32_i24).  Both operands MUST fit 24 signed bits; the
  * explicit sign extensions tell the compiler so and cost nothing (the instruction ignores the
  * upper byte).  Native code rather than inline asm: the hazard recogniser pads every asm result
  * with an s_nop, and a wave pays ~4 cycles for each. */
 __device__ __forceinline__ int32_t sx24(int32_t v) { return (int32_t)((uint32_t)v << 8) >> 8; }
-__device__ __forceinline__ int32_t opaque(int32_t v)
-{
-  asm("" : "+v"(v)); /* emits nothing; only hides the value from reassociation */
-  return v;
-}
 __device__ __forceinline__ int32_t mad_i24(int32_t a, int32_t b, int32_t c)
 {
   return (int32_t)((uint32_t)(sx24(a) * sx24(b)) + (uint32_t)c);
 }
 
 /* (16384 + sum h*w) >> 15 with int32 wraparound - reference src/aad_encoder.c:359-363.
- * FAST24: the caller has checked |w| < 2^23 for the whole chunk, so the 24-bit multiplier gives
- * the exact products; otherwise full 32-bit multiplies (exact for ANY weights). */
-template <bool FAST24>
+ * Full 32-bit multiplies: exact for ANY weights, and on gfx950 v_mul_lo_u32 issues at the same
+ * rate as the 24-bit forms (tools/microbench), so a guarded 24-bit fast path buys nothing. */
 __device__ __forceinline__ int32_t predict(const Lane &L)
 {
-  if (FAST24) { /* a chain of four v_mad_i32_i24; opaque() stops the compiler from turning it into 4 mul + 2 add3 */
-    int32_t acc = mad_i24(L.h0, L.w0, 16384);
-    acc = mad_i24(L.h1, L.w1, opaque(acc));
-    acc = mad_i24(L.h2, L.w2, opaque(acc));
-    acc = mad_i24(L.h3, L.w3, opaque(acc));
-    return acc >> 15;
-  }
   uint32_t acc = 16384u;
   acc += (uint32_t)L.h0 * (uint32_t)L.w0;
   acc += (uint32_t)L.h1 * (uint32_t)L.w1;
@@ -175,20 +189,10 @@ __device__ __forceinline__ int32_t predict(const Lane &L)
   return (int32_t)acc >> 15;
 }
 
-/* Per-step weight change is at most (61438 * 32768 + 16384) >> 18 = 7680 < 2^13, so weights that
- * start a 16-sample chunk below 2^22 in magnitude stay below 2^23 throughout it. */
-__device__ __forceinline__ bool weights_fit_24(const Lane &L)
+/* LMS and history update - reference src/aad_encoder.c:396-406, src/aad_decoder.c:306-315.
+ * qd*h fits 32 bits (|qd| <= 61438, |h| <= 32768), so the 24-bit multiplier is exact. */
+__device__ __forceinline__ void lms_and_shift(Lane &L, int32_t qd, int32_t y)
 {
-  constexpr uint32_t T = 1u << 22;
-  return (((uint32_t)L.w0 + T) | ((uint32_t)L.w1 + T) | ((uint32_t)L.w2 + T) | ((uint32_t)L.w3 + T)) < 2u * T;
-}
-
-/* step-index, LMS and history update - reference src/aad_encoder.c:386-406, src/aad_decoder.c:303-315.
- * m21 = 2*mag + 1 addresses the int16 delta table: byte offset 2*mag = m21 - 1. */
-__device__ __forceinline__ void advance(Lane &L, uint32_t m21, int32_t qd, int32_t y, const char *lds)
-{
-  const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDeltaOff - 1) + m21);
-  L.idxb = min(max(L.idxb + delta, kIdxMin), kIdxMax);
   L.w0 += mad_i24(qd, L.h0, 16384) >> 18;
   L.w1 += mad_i24(qd, L.h1, 16384) >> 18;
   L.w2 += mad_i24(qd, L.h2, 16384) >> 18;
@@ -200,37 +204,41 @@ __device__ __forceinline__ void advance(Lane &L, uint32_t m21, int32_t qd, int32
 }
 
 /* one encoder step - reference src/aad_encoder.c:343-410.  Returns the code; qd is the
- * dequantised difference (the reference's quantize_error). */
-template <int BITS, bool FAST24>
+ * dequantised difference (the reference's quantize_error).  Plain form, used for tails and the
+ * trial search; the bulk goes through encode_chunk16. */
+template <int BITS>
 __device__ __forceinline__ uint32_t encode_step(Lane &L, int32_t x, const char *lds, int32_t &qd)
 {
-  const u32x4 e = *reinterpret_cast<const u32x4 *>(lds + (L.idxb & 0xFF0));
-  const int32_t p = predict<FAST24>(L);
+  const uint32_t sa = slot_addr(L.idxb);
+  const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
+  const float hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
+  const float hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+  const int32_t p = predict(L);
   const int32_t d = x - p;
   const int32_t m = d >> 31; /* 0 or -1 */
   /* min((|d| << (BITS-2)) / step, magmax) == min(trunc(fma(|d|, 2^(BITS-1)*hr, hr)), magmax), hr = fl32(0.5/step) */
-  const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf((float)d), __uint_as_float(e.z), __uint_as_float(e.y)),
-                           Pack<BITS>::kMagMax);
+  const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf((float)d), hs, hr), Pack<BITS>::kMagMax);
   const uint32_t m21 = (mag << 1) | 1u;
-  const int32_t q = (int32_t)(__umul24(e.x, m21) >> (BITS - 1));
+  const int32_t q = (int32_t)(__umul24(step, m21) >> (BITS - 1));
   qd = (q ^ m) - m;
-  advance(L, m21, qd, clip16(qd + p), lds);
+  /* m21 = 2*mag + 1 addresses the int16 delta table: byte offset 2*mag = m21 - 1 */
+  const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDeltaOff - 1) + m21);
+  L.idxb = clamp_idx(L.idxb + delta);
+  lms_and_shift(L, qd, clip16(qd + p));
   return mag | ((uint32_t)m & Pack<BITS>::kSign);
 }
 
-/* one decoder step - reference src/aad_decoder.c:269-318.  `word` holds big-endian packed codes,
- * POS is the bit position of this sample's code in it. */
-template <int BITS, int POS, bool FAST24>
-__device__ __forceinline__ int32_t decode_step(Lane &L, uint32_t word, const char *lds)
+/* one decoder step - reference src/aad_decoder.c:269-318; `code` in the low BITS bits.  Plain
+ * form for tails; the bulk goes through decode_chunk16. */
+template <int BITS>
+__device__ __forceinline__ int32_t decode_step(Lane &L, uint32_t code, const char *lds)
 {
-  const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + (L.idxb & 0xFF0));
-  constexpr uint32_t kMask2 = Pack<BITS>::kMagMax << 1;
-  const uint32_t m21 = ((POS >= 1 ? word >> (POS >= 1 ? POS - 1 : 0) : word << 1) & kMask2) | 1u;
-  const int32_t m = (int32_t)(word << (31 - (POS + BITS - 1))) >> 31;
-  const int32_t q = (int32_t)(__umul24(step, m21) >> (BITS - 1));
-  const int32_t qd = (q ^ m) - m;
-  const int32_t y = clip16(qd + predict<FAST24>(L));
-  advance(L, m21, qd, y, lds);
+  const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
+  const u32x3 t = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + ((code & ((1u << BITS) - 1u)) << 4));
+  const int32_t qd = mad_i24((int32_t)step, (int32_t)t.x, (int32_t)t.y) >> (BITS - 1);
+  const int32_t y = clip16(qd + predict(L));
+  L.idxb = clamp_idx(L.idxb + (int32_t)t.z);
+  lms_and_shift(L, qd, y);
   return y;
 }
 
@@ -239,42 +247,51 @@ __device__ __forceinline__ int32_t decode_step(Lane &L, uint32_t word, const cha
  * dependent LDS lookups per sample (code -> index delta -> step record of the NEXT sample), ~55
  * cycles each for a lone wave.  The compiler's schedule waits for both right after issuing
  * them; here every sample is cut into four regions separated by scheduling barriers so that
- * each lookup has ~14 independent instructions (~60 cycles) issued behind it:
+ * each lookup has ~15 independent instructions (~60 cycles) issued behind it:
  *   A  quantise with the step record fetched during the previous sample; start the delta lookup
  *   B  dequantise, reconstruct, LMS taps 0-1, pack the code            (hides the delta lookup)
  *   C  new step index; start the lookup of the next sample's step record
  *   D  LMS taps 2-3, history shift, predict + difference of the NEXT sample (hides the record lookup)
  * Same arithmetic as encode_step, instruction for instruction.
  */
-template <int BITS, bool FAST24>
+template <int BITS>
 __device__ __forceinline__ void encode_chunk16(Lane &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out)
 {
-  /* 12 of the record's 16 bytes: a b128 read would also tie up a 4th register until it lands */
-  u32x3 e = *reinterpret_cast<const u32x3 *>(lds + (L.idxb & 0xFF0));
-  int32_t p = predict<FAST24>(L);
+  uint32_t sa = slot_addr(L.idxb);
+  uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
+  float hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
+  float hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+  int32_t p = predict(L);
   int32_t d = x[0] - p;
   int32_t m = d >> 31;
   float f = (float)d;
   static_for<0, kChunk>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     /* A */
-    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)),
-                             Pack<BITS>::kMagMax);
+    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), hs, hr), Pack<BITS>::kMagMax);
     const uint32_t m21 = (mag << 1) | 1u;
     const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDeltaOff - 1) + m21);
     __builtin_amdgcn_sched_barrier(0);
     /* B */
-    const int32_t q = (int32_t)(__umul24(e.x, m21) >> (BITS - 1));
+    const int32_t q = (int32_t)(__umul24(step, m21) >> (BITS - 1));
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
     L.w0 += mad_i24(qd, L.h0, 16384) >> 18;
     L.w1 += mad_i24(qd, L.h1, 16384) >> 18;
     uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
     acc = (acc << BITS) | mag | ((uint32_t)m & Pack<BITS>::kSign);
+    pin(L.w0);
+    pin(L.w1);
+    pin(acc);
     __builtin_amdgcn_sched_barrier(0);
     /* C */
-    L.idxb = min(max(L.idxb + delta, kIdxMin), kIdxMax);
-    if (j + 1 < kChunk) e = *reinterpret_cast<const u32x3 *>(lds + (L.idxb & 0xFF0));
+    L.idxb = clamp_idx(L.idxb + delta);
+    if (j + 1 < kChunk) {
+      sa = slot_addr(L.idxb);
+      step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
+      hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
+      hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+    }
     __builtin_amdgcn_sched_barrier(0);
     /* D */
     L.w2 += mad_i24(qd, L.h2, 16384) >> 18;
@@ -284,13 +301,67 @@ __device__ __forceinline__ void encode_chunk16(Lane &L, const int32_t *x, const 
     L.h1 = L.h0;
     L.h0 = y;
     if (j + 1 < kChunk) {
-      p = predict<FAST24>(L);
+      p = predict(L);
       d = x[j + 1] - p;
       m = d >> 31;
       f = (float)d;
+      pin(m);
+      pin(f);
     } else {
       qd_out = qd;
+      pin(L.w2);
+      pin(L.w3);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+/*
+ * Sixteen decoder steps, software-pipelined by hand.  Codes are known a chunk ahead, so the
+ * per-code record of sample j+2 is fetched during sample j; the only lookup on the recurrence
+ * is the step size of the next sample, started as soon as the new index is known and hidden
+ * behind this sample's reconstruction, LMS update and the next prediction (~22 instructions).
+ *   A  step index of the next sample; start its step lookup and the record lookup of sample j+2
+ *   B  dequantise (mad + shift), reconstruct, LMS, history shift, predict the next sample
+ */
+template <int BITS, typename Finish>
+__device__ __forceinline__ void decode_chunk16(Lane &L, const uint32_t *w, const char *lds, int32_t *y, Finish finish)
+{
+  constexpr int cpw = Pack<BITS>::kCodesPerWord;
+  auto code_addr = [&](int j) -> uint32_t { /* (code << 4) for sample j, j compile-time after unrolling */
+    const int pos = Pack<BITS>::pos(j % cpw);
+    const uint32_t word = w[j / cpw];
+    return (pos >= 4 ? word >> (pos >= 4 ? pos - 4 : 0) : word << (4 - pos)) & (((1u << BITS) - 1u) << 4);
+  };
+  uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
+  /* per-code records two samples ahead: they depend on nothing but the code bits */
+  u32x3 t0 = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(0));
+  u32x3 t1 = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(1));
+  int32_t p = predict(L);
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    /* A */
+    const uint32_t step_j = step;
+    const u32x3 t_j = t0;
+    t0 = t1;
+    L.idxb = clamp_idx(L.idxb + (int32_t)t_j.z);
+    if (j + 1 < kChunk) step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
+    if (j + 2 < kChunk) t1 = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(j + 2 < kChunk ? j + 2 : j));
+    __builtin_amdgcn_sched_barrier(0);
+    /* B */
+    const int32_t qd = mad_i24((int32_t)step_j, (int32_t)t_j.x, (int32_t)t_j.y) >> (BITS - 1);
+    const int32_t yy = clip16(qd + p);
+    lms_and_shift(L, qd, yy);
+    if (j + 1 < kChunk) {
+      p = predict(L);
+      pin(p);
+    } else {
+      pin(L.w0);
+      pin(L.w1);
+      pin(L.w2);
+      pin(L.w3);
+    }
+    y[j] = finish(yy);
     __builtin_amdgcn_sched_barrier(0);
   });
 }
@@ -539,14 +610,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       if (k + 1 < full) cp += kStride;
       next.load(cp);
       int32_t y[kChunk];
-      auto body16 = [&](auto fast) {
-        static_for<0, kChunk>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          constexpr int cpw = Pack<BITS>::kCodesPerWord;
-          y[j] = finish(decode_step<BITS, Pack<BITS>::pos(j % cpw), decltype(fast)::value>(L, w[j / cpw], lds));
-        });
-      };
-      if (weights_fit_24(L)) body16(std::true_type{}); else body16(std::false_type{});
+      decode_chunk16<BITS>(L, w, lds, y, finish);
       next.touch();
       store_chunk_pcm<CHF>(op, y, c, ch);
       op += (uint64_t)kChunk * ch;
@@ -566,7 +630,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       acc <<= 32 - 8 * UB; /* codes to the top of the word */
 #pragma unroll
       for (int k = 0; k < US; k++) {
-        const int32_t y = finish(decode_step<BITS, 32 - BITS, false>(L, acc, lds));
+        const int32_t y = finish(decode_step<BITS>(L, acc >> (32 - BITS), lds));
         acc <<= BITS;
         if (i + k < coded) dst[(uint64_t)(kTaps + i + k) * ch] = (int16_t)y;
       }
@@ -674,7 +738,7 @@ __device__ __forceinline__ double rmse_pass(Lane &L, const Src &src, uint64_t fi
   int64_t sum = 0;
   for (uint32_t i = kTaps; i < n; i++) {
     int32_t qd;
-    encode_step<BITS, false>(L, src.at(first + i), lds, qd);
+    encode_step<BITS>(L, src.at(first + i), lds, qd);
     sum += (int64_t)(int32_t)((uint32_t)qd * (uint32_t)qd);
   }
   return sqrt((double)sum / (double)n);
@@ -837,8 +901,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
         if (k + 1 < full) xp += (uint64_t)kChunk * ch;
         next.load(xp, ch, c);
         uint32_t w[2] = {0, 0};
-        if (weights_fit_24(L)) encode_chunk16<BITS, true>(L, x, lds, w, last_qd);
-        else encode_chunk16<BITS, false>(L, x, lds, w, last_qd);
+        encode_chunk16<BITS>(L, x, lds, w, last_qd);
         next.touch();
         if (CHF != 0) {
           store_chunk_codes<BITS, (CHF ? CHF : 1)>(body + (uint64_t)k * kOutStride * ch, w, c);
@@ -864,7 +927,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 #pragma unroll
       for (int k = 0; k < US; k++) {
         const int32_t x = i + k < coded ? src.at(first + kTaps + i + k) : 0;
-        acc = (acc << BITS) | encode_step<BITS, false>(L, x, lds, last_qd);
+        acc = (acc << BITS) | encode_step<BITS>(L, x, lds, last_qd);
       }
 #pragma unroll
       for (int k = 0; k < UB; k++) up[k] = (uint8_t)(acc >> (8 * (UB - 1 - k)));

@@ -26,7 +26,7 @@
     uint64_t best = ~0ull;                                                             \
     for (int it = 0; it < 6; it++) {                                                   \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory"); \
-      asm volatile(R256(BODY) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(fa), "+v"(fb), "+v"(l0), "+v"(l1) :: "memory", "vcc", "s20", "s21"); \
+      asm volatile(R256(BODY) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(fa), "+v"(fb), "+v"(l0), "+v"(l1) :: "memory", "vcc", "s20", "s21", "v200", "v201", "v202"); \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory"); \
       if (t1 - t0 < best) best = t1 - t0;                                              \
     }                                                                                  \
@@ -82,6 +82,18 @@ DEFINE_TEST(gstore_short,   "global_store_short %10, %0, off\n global_store_shor
 DEFINE_TEST(gstore_dwordx2, "global_store_dwordx2 %10, %11, off\n")
 DEFINE_TEST(ds_read_issue,  "ds_read_b32 %1, %0\n ds_read_b32 %2, %0 offset:16\n ds_read_b32 %3, %0 offset:32\n ds_read_b32 %4, %0 offset:48\n")
 DEFINE_TEST(waitcnt_only,   "s_waitcnt lgkmcnt(0)\n")
+DEFINE_TEST(lds_lat_0, "ds_read_b32 %5, %0\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0x3fc, %5\n")
+DEFINE_TEST(lds_lat_4, "ds_read_b32 %5, %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0x3fc, %5\n")
+DEFINE_TEST(lds_lat_8, "ds_read_b32 %5, %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0x3fc, %5\n")
+DEFINE_TEST(lds_lat_12, "ds_read_b32 %5, %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0x3fc, %5\n")
+DEFINE_TEST(lds_lat_16, "ds_read_b32 %5, %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0x3fc, %5\n")
+DEFINE_TEST(lds_lat_20, "ds_read_b32 %5, %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0x3fc, %5\n")
+DEFINE_TEST(lds_lat_24, "ds_read_b32 %5, %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0x3fc, %5\n")
+DEFINE_TEST(lds_lat_32, "ds_read_b32 %5, %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0x3fc, %5\n")
+DEFINE_TEST(lds96_lat_0, "ds_read_b96 v[200:202], %0\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0xf0, v200\n")
+DEFINE_TEST(lds96_lat_8, "ds_read_b96 v[200:202], %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0xf0, v200\n")
+DEFINE_TEST(lds96_lat_16, "ds_read_b96 v[200:202], %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0xf0, v200\n")
+DEFINE_TEST(lds96_lat_24, "ds_read_b96 v[200:202], %0\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0xf0, v200\n")
 DEFINE_TEST(add_f64,        "v_add_f64 %10, %10, %11\n")
 
 __global__ void k_clock(uint64_t *out) {
@@ -101,7 +113,7 @@ int main() {
   std::vector<T> tests = { E(add_dep,1), E(add_ind4,4), E(mad24_dep,1), E(mad24_ind4,4), E(mullo_dep,1), E(mullo_ind4,4),
     E(mulhi24_ind4,4), E(mulhi32_ind4,4), E(med3_dep,1), E(add3_dep,1), E(xad_dep,1), E(ashr_add,2), E(cvt_mul_cvt,3), E(cvtf_ind,2),
     E(cmp_cndmask,2), E(bfe_ind,2), E(perm_ind,2), E(dpp_mov,1), E(dpp_add_dep,1), E(dpp_add_ind,2), E(sdwa_sub,2),
-    E(madu64_ind2,1), E(madu64_dep,1), E(pred_madu64,5), E(pred_mullo,7), E(pred_mad24,5), E(pred_quad_dpp,4), E(cndmask_dpp,1), E(fma_abs,4), E(lms3,3), E(ds_read_b128_dep,2), E(gstore_short,2), E(gstore_dwordx2,1), E(ds_read_issue,4), E(waitcnt_only,1), E(add_f64,1), E(ds_read_dep,1), E(ds_read_b64_ind,2), E(salu_mix,2), E(salu_only,2), E(snop,1), E(pk_add_i16,1), E(mad_i32_i16,1),
+    E(madu64_ind2,1), E(madu64_dep,1), E(pred_madu64,5), E(pred_mullo,7), E(pred_mad24,5), E(pred_quad_dpp,4), E(cndmask_dpp,1), E(fma_abs,4), E(lms3,3), E(ds_read_b128_dep,2), E(lds_lat_0,3), E(lds_lat_4,7), E(lds_lat_8,11), E(lds_lat_12,15), E(lds_lat_16,19), E(lds_lat_20,23), E(lds_lat_24,27), E(lds_lat_32,35), E(lds96_lat_0,3), E(lds96_lat_8,11), E(lds96_lat_16,19), E(lds96_lat_24,27),  E(gstore_short,2), E(gstore_dwordx2,1), E(ds_read_issue,4), E(waitcnt_only,1), E(add_f64,1), E(ds_read_dep,1), E(ds_read_b64_ind,2), E(salu_mix,2), E(salu_only,2), E(snop,1), E(pk_add_i16,1), E(mad_i32_i16,1),
     E(dot2_i32_i16,1), E(lshl_add,1), E(lshl_or,1), E(and_or,1), E(min_u32,1) };
   for (int rep = 0; rep < 3; rep++) {
     hipLaunchKernelGGL(k_clock, dim3(1), dim3(64), 0, 0, d_out);
@@ -113,8 +125,8 @@ int main() {
   for (auto &t : tests) {
     double res[3];
     printf("%-18s", t.name); fflush(stdout);
-    int cfg_threads[3] = {64, 256, 512};   // 1 wave; 8 waves = 2/SIMD; 16 waves = 4/SIMD (x2 blocks -> 8/SIMD)
-    int cfg_blocks[3] = {1, 256, 1024};
+    int cfg_threads[3] = {64, 256, 256};   // 1 wave; 8 waves = 2/SIMD; 16 waves = 4/SIMD (x2 blocks -> 8/SIMD)
+    int cfg_blocks[3] = {1, 256, 512};
     for (int c = 0; c < 3; c++) {
       hipMemset(d_out, 0, sizeof(uint64_t) * 4096);
       hipLaunchKernelGGL(t.fn, dim3(cfg_blocks[c]), dim3(cfg_threads[c]), 0, 0, d_out, d_sink, 7);
