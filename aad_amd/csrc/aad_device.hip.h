@@ -100,7 +100,7 @@ struct LaneStateRecord {
   int32_t quantize_error;
 };
 
-struct Lane {
+struct Lane { /* one lane = one whole recurrence */
   int32_t w0, w1, w2, w3; /* Q15 LMS weights */
   int32_t h0, h1, h2, h3; /* history, h0 newest */
   int32_t idxb;           /* Q4 step index + kIdxBias */
@@ -203,11 +203,120 @@ __device__ __forceinline__ void lms_and_shift(Lane &L, int32_t qd, int32_t y)
   L.h0 = y;
 }
 
+/* LMS split in two halves for the hand-pipelined encoder (taps 0-1, then taps 2-3 + shift) */
+__device__ __forceinline__ void lms_first(Lane &L, int32_t qd)
+{
+  L.w0 += mad_i24(qd, L.h0, 16384) >> 18;
+  L.w1 += mad_i24(qd, L.h1, 16384) >> 18;
+}
+__device__ __forceinline__ void lms_rest_and_shift(Lane &L, int32_t qd, int32_t y)
+{
+  L.w2 += mad_i24(qd, L.h2, 16384) >> 18;
+  L.w3 += mad_i24(qd, L.h3, 16384) >> 18;
+  L.h3 = L.h2;
+  L.h2 = L.h1;
+  L.h1 = L.h0;
+  L.h0 = y;
+}
+__device__ __forceinline__ void pin_weights(Lane &L)
+{
+  pin(L.w0);
+  pin(L.w1);
+  pin(L.w2);
+  pin(L.w3);
+}
+
+/*
+ * "Quad" mapping: FOUR adjacent lanes share one recurrence, lane t of the quad owning tap t
+ * (weight w_t, history sample h_t); everything else is replicated.  The LMS update becomes 3
+ * instructions instead of 12, the prediction one multiply-add and two DPP butterfly adds instead
+ * of 4 multiplies and 2 three-operand adds, the history shift one DPP move and a select.  A
+ * wave pays ~4.7 cycles per instruction whatever it is, and every BASELINE batch leaves most of
+ * the chip's lanes idle, so spending 4x the lanes to cut the per-sample instruction count by a
+ * third is a pure win there; the host picks this mapping while the batch is small.
+ */
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_dpp(uint32_t v)
+{
+  /* old = 0 + bound_ctrl lets the compiler fold the move into the consuming VOP2 (v_add_u32_dpp) */
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+struct QuadLane {
+  int32_t w, h;    /* this lane's tap */
+  int32_t idxb;    /* replicated */
+  uint32_t round;  /* 16384 in tap 0, 0 elsewhere: the prediction's rounding term enters the sum once */
+  bool tap0;
+};
+
+__device__ __forceinline__ int32_t predict(const QuadLane &Q)
+{
+  uint32_t s = (uint32_t)Q.h * (uint32_t)Q.w + Q.round;
+  s += quad_dpp<0xB1>(s); /* quad_perm [1,0,3,2] */
+  s += quad_dpp<0x4E>(s); /* quad_perm [2,3,0,1] */
+  return (int32_t)s >> 15;
+}
+__device__ __forceinline__ void lms_first(QuadLane &Q, int32_t qd) { Q.w += mad_i24(qd, Q.h, 16384) >> 18; }
+__device__ __forceinline__ void lms_rest_and_shift(QuadLane &Q, int32_t, int32_t y)
+{
+  const int32_t up = (int32_t)quad_dpp<0x90>((uint32_t)Q.h); /* quad_perm [0,0,1,2]: the next-older tap's sample */
+  Q.h = Q.tap0 ? y : up;
+}
+__device__ __forceinline__ void lms_and_shift(QuadLane &Q, int32_t qd, int32_t y)
+{
+  lms_first(Q, qd);
+  lms_rest_and_shift(Q, qd, y);
+}
+__device__ __forceinline__ void pin_weights(QuadLane &Q) { pin(Q.w); }
+
+/* full state <-> quad (block boundaries only) */
+__device__ __forceinline__ QuadLane to_quad(const Lane &L, uint32_t tap)
+{
+  QuadLane Q;
+  Q.w = tap == 0 ? L.w0 : (tap == 1 ? L.w1 : (tap == 2 ? L.w2 : L.w3));
+  Q.h = tap == 0 ? L.h0 : (tap == 1 ? L.h1 : (tap == 2 ? L.h2 : L.h3));
+  Q.idxb = L.idxb;
+  Q.round = tap == 0 ? 16384u : 0u;
+  Q.tap0 = tap == 0;
+  return Q;
+}
+__device__ __forceinline__ Lane from_quad(const QuadLane &Q)
+{
+  Lane L;
+  L.w0 = (int32_t)quad_dpp<0x00>((uint32_t)Q.w);
+  L.w1 = (int32_t)quad_dpp<0x55>((uint32_t)Q.w);
+  L.w2 = (int32_t)quad_dpp<0xAA>((uint32_t)Q.w);
+  L.w3 = (int32_t)quad_dpp<0xFF>((uint32_t)Q.w);
+  L.h0 = (int32_t)quad_dpp<0x00>((uint32_t)Q.h);
+  L.h1 = (int32_t)quad_dpp<0x55>((uint32_t)Q.h);
+  L.h2 = (int32_t)quad_dpp<0xAA>((uint32_t)Q.h);
+  L.h3 = (int32_t)quad_dpp<0xFF>((uint32_t)Q.h);
+  L.idxb = Q.idxb;
+  return L;
+}
+
+/* Q4 step-index delta of a magnitude code as arithmetic (the constants of reference
+ * src/aad_tables.c:8-45): 4-bit {-18,-17,-14,16,32,64,128,256}, 3-bit {-16,-15,32,128},
+ * 2-bit {-14,40}.  Five instructions instead of an LDS lookup: used where that lookup would sit
+ * on the recurrence's critical path and there are instruction slots to spare (quad encoder). */
+template <int BITS>
+__device__ __forceinline__ int32_t index_delta_arith(uint32_t mag)
+{
+  if (BITS == 4) {
+    const int32_t t = (int32_t)(2u << mag);
+    return mag < 3 ? t - (int32_t)(mag + 20u) : t;
+  } else if (BITS == 3) {
+    return mag < 2 ? (int32_t)mag - 16 : (int32_t)(2u << (2u * mag));
+  } else {
+    return mag ? 40 : -14;
+  }
+}
+
 /* one encoder step - reference src/aad_encoder.c:343-410.  Returns the code; qd is the
  * dequantised difference (the reference's quantize_error).  Plain form, used for tails and the
- * trial search; the bulk goes through encode_chunk16. */
-template <int BITS>
-__device__ __forceinline__ uint32_t encode_step(Lane &L, int32_t x, const char *lds, int32_t &qd)
+ * trial search; the bulk goes through encode_chunk16.  S = Lane or QuadLane. */
+template <int BITS, typename S>
+__device__ __forceinline__ uint32_t encode_step(S &L, int32_t x, const char *lds, int32_t &qd)
 {
   const uint32_t sa = slot_addr(L.idxb);
   const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
@@ -230,8 +339,8 @@ __device__ __forceinline__ uint32_t encode_step(Lane &L, int32_t x, const char *
 
 /* one decoder step - reference src/aad_decoder.c:269-318; `code` in the low BITS bits.  Plain
  * form for tails; the bulk goes through decode_chunk16. */
-template <int BITS>
-__device__ __forceinline__ int32_t decode_step(Lane &L, uint32_t code, const char *lds)
+template <int BITS, typename S>
+__device__ __forceinline__ int32_t decode_step(S &L, uint32_t code, const char *lds)
 {
   const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
   const u32x3 t = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + ((code & ((1u << BITS) - 1u)) << 4));
@@ -254,8 +363,8 @@ __device__ __forceinline__ int32_t decode_step(Lane &L, uint32_t code, const cha
  *   D  LMS taps 2-3, history shift, predict + difference of the NEXT sample (hides the record lookup)
  * Same arithmetic as encode_step, instruction for instruction.
  */
-template <int BITS>
-__device__ __forceinline__ void encode_chunk16(Lane &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out)
+template <int BITS, typename S>
+__device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out)
 {
   uint32_t sa = slot_addr(L.idxb);
   uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
@@ -276,12 +385,10 @@ __device__ __forceinline__ void encode_chunk16(Lane &L, const int32_t *x, const 
     const int32_t q = (int32_t)(__umul24(step, m21) >> (BITS - 1));
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
-    L.w0 += mad_i24(qd, L.h0, 16384) >> 18;
-    L.w1 += mad_i24(qd, L.h1, 16384) >> 18;
+    lms_first(L, qd);
     uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
     acc = (acc << BITS) | mag | ((uint32_t)m & Pack<BITS>::kSign);
-    pin(L.w0);
-    pin(L.w1);
+    pin_weights(L);
     pin(acc);
     __builtin_amdgcn_sched_barrier(0);
     /* C */
@@ -294,12 +401,7 @@ __device__ __forceinline__ void encode_chunk16(Lane &L, const int32_t *x, const 
     }
     __builtin_amdgcn_sched_barrier(0);
     /* D */
-    L.w2 += mad_i24(qd, L.h2, 16384) >> 18;
-    L.w3 += mad_i24(qd, L.h3, 16384) >> 18;
-    L.h3 = L.h2;
-    L.h2 = L.h1;
-    L.h1 = L.h0;
-    L.h0 = y;
+    lms_rest_and_shift(L, qd, y);
     if (j + 1 < kChunk) {
       p = predict(L);
       d = x[j + 1] - p;
@@ -309,9 +411,64 @@ __device__ __forceinline__ void encode_chunk16(Lane &L, const int32_t *x, const 
       pin(f);
     } else {
       qd_out = qd;
-      pin(L.w2);
-      pin(L.w3);
+      pin_weights(L);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+/*
+ * Sixteen encoder steps for the quad mapping.  With the LMS and the prediction down to a few
+ * instructions the two dependent LDS lookups of encode_chunk16 would bound the sample (~190
+ * cycles); here the index delta is arithmetic, so the only lookup on the recurrence is the next
+ * step record, started right after the quantiser and hidden behind everything else:
+ *   A  quantise, delta, new step index; start the lookup of the next sample's step record
+ *   B  dequantise, reconstruct, LMS, history shift, pack the code, predict + difference of the next sample
+ */
+template <int BITS>
+__device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out)
+{
+  uint32_t sa = slot_addr(L.idxb);
+  uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
+  float hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
+  float hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+  int32_t p = predict(L);
+  int32_t d = x[0] - p;
+  int32_t m = d >> 31;
+  float f = (float)d;
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    /* A */
+    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), hs, hr), Pack<BITS>::kMagMax);
+    const uint32_t step_j = step;
+    L.idxb = clamp_idx(L.idxb + index_delta_arith<BITS>(mag));
+    if (j + 1 < kChunk) {
+      sa = slot_addr(L.idxb);
+      step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
+      hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
+      hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    /* B */
+    const uint32_t m21 = (mag << 1) | 1u;
+    const int32_t q = (int32_t)(__umul24(step_j, m21) >> (BITS - 1));
+    const int32_t qd = (q ^ m) - m;
+    const int32_t y = clip16(qd + p);
+    uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
+    acc = (acc << BITS) | mag | ((uint32_t)m & Pack<BITS>::kSign);
+    lms_and_shift(L, qd, y);
+    if (j + 1 < kChunk) {
+      p = predict(L);
+      d = x[j + 1] - p;
+      m = d >> 31;
+      f = (float)d;
+      pin(m);
+      pin(f);
+    } else {
+      qd_out = qd;
+      pin_weights(L);
+    }
+    pin(acc);
     __builtin_amdgcn_sched_barrier(0);
   });
 }
@@ -324,8 +481,8 @@ __device__ __forceinline__ void encode_chunk16(Lane &L, const int32_t *x, const 
  *   A  step index of the next sample; start its step lookup and the record lookup of sample j+2
  *   B  dequantise (mad + shift), reconstruct, LMS, history shift, predict the next sample
  */
-template <int BITS, typename Finish>
-__device__ __forceinline__ void decode_chunk16(Lane &L, const uint32_t *w, const char *lds, int32_t *y, Finish finish)
+template <int BITS, typename S, typename Finish>
+__device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const char *lds, int32_t *y, Finish finish)
 {
   constexpr int cpw = Pack<BITS>::kCodesPerWord;
   auto code_addr = [&](int j) -> uint32_t { /* (code << 4) for sample j, j compile-time after unrolling */
@@ -356,10 +513,7 @@ __device__ __forceinline__ void decode_chunk16(Lane &L, const uint32_t *w, const
       p = predict(L);
       pin(p);
     } else {
-      pin(L.w0);
-      pin(L.w1);
-      pin(L.w2);
-      pin(L.w3);
+      pin_weights(L);
     }
     y[j] = finish(yy);
     __builtin_amdgcn_sched_barrier(0);
@@ -372,8 +526,10 @@ __device__ __forceinline__ void decode_chunk16(Lane &L, const uint32_t *w, const
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 /* value of the neighbouring lane (lane ^ 1): the other channel of a stereo pair */
+template <bool QUAD>
 __device__ __forceinline__ uint32_t pair_swap(uint32_t v)
 {
+  if (QUAD) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F); /* lane ^ 4: the same tap of the other channel's quad */
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
 }
 
@@ -474,7 +630,7 @@ struct ChunkCodes {
  * stores.  Stereo: the two lanes of a pair trade half of their packed samples through DPP and
  * each writes 2 x 16 contiguous bytes of L/R frames.  A vector-memory instruction costs a lone
  * wave ~17 cycles to issue whatever its width, so few wide stores beat one short per sample. */
-template <int CHF>
+template <int CHF, bool QUAD>
 __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *y, uint32_t c, uint32_t ch)
 {
   if (CHF == 1) {
@@ -496,7 +652,7 @@ __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *
       const uint32_t p1 = perm((uint32_t)y[8 * h + 3], (uint32_t)y[8 * h + 2], 0x05040100);
       const uint32_t p2 = perm((uint32_t)y[8 * h + 5], (uint32_t)y[8 * h + 4], 0x05040100);
       const uint32_t p3 = perm((uint32_t)y[8 * h + 7], (uint32_t)y[8 * h + 6], 0x05040100);
-      const uint32_t ra = pair_swap(c ? p0 : p2), rb = pair_swap(c ? p1 : p3);
+      const uint32_t ra = pair_swap<QUAD>(c ? p0 : p2), rb = pair_swap<QUAD>(c ? p1 : p3);
       const uint32_t ka = c ? p2 : p0, kb = c ? p3 : p1;
       u32x4 v;
       v.x = perm(ka, ra, sel_lo);
@@ -515,14 +671,18 @@ __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *
  * Block-parallel decode (reference src/aad_decoder.c:321-475, looped by :514-534).
  * CHF: 1 / 2 = specialised channel counts with wide chunk loads, 0 = any channel count (byte loads).
  */
-template <int BITS, int CHF, bool MS>
+template <int BITS, int CHF, bool MS, bool QUAD>
 __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
 {
+  static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   stage_tables<BITS>(lds);
 
   const uint32_t ch = CHF ? CHF : a.channels;
-  const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t lane = QUAD ? thread >> 2 : thread; /* index of the (block, channel) recurrence */
+  const uint32_t tap = QUAD ? threadIdx.x & 3u : 0u;
+  const bool writer = tap == 0;                      /* quad: all four lanes hold the samples, one stores them */
   const bool active = lane < a.total_blocks * ch;
   const uint64_t g = active ? lane / ch : 0;
   const uint32_t c = active ? (uint32_t)(lane % ch) : 0;
@@ -544,27 +704,28 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
   int16_t *dst = a.pcm + sd.pcm_offset + first * ch + c;
   if (avail < (uint32_t)kBlockHeaderBytesPerCh * ch) n = 0; /* DecodeBlock: INSUFFICIENT_DATA (reported by the host) */
 
-  Lane L = {0, 0, 0, 0, 0, 0, 0, 0, kIdxBias};
+  Lane H = {0, 0, 0, 0, 0, 0, 0, 0, kIdxBias};
   if (n) { /* block header - reference src/aad_decoder.c:364-380 */
     const uint8_t *hp = src + c * kBlockHeaderBytesPerCh;
     const uint32_t v = load_be16(hp);
-    L.idxb = min((int32_t)(v >> 4), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias;
+    H.idxb = min((int32_t)(v >> 4), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias;
     const uint32_t shift = v & 0xFu;
-    L.w0 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 2) << shift);
-    L.h0 = (int16_t)load_be16(hp + 4);
-    L.w1 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 6) << shift);
-    L.h1 = (int16_t)load_be16(hp + 8);
-    L.w2 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 10) << shift);
-    L.h2 = (int16_t)load_be16(hp + 12);
-    L.w3 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 14) << shift);
-    L.h3 = (int16_t)load_be16(hp + 16);
+    H.w0 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 2) << shift);
+    H.h0 = (int16_t)load_be16(hp + 4);
+    H.w1 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 6) << shift);
+    H.h1 = (int16_t)load_be16(hp + 8);
+    H.w2 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 10) << shift);
+    H.h2 = (int16_t)load_be16(hp + 12);
+    H.w3 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 14) << shift);
+    H.h3 = (int16_t)load_be16(hp + 16);
   }
 
-  /* inverse mid/side needs the partner channel's sample: lanes c=0/1 of a block are neighbours
-   * and run the same trip counts, so the swap always meets an active lane */
+  /* inverse mid/side needs the partner channel's sample: the lanes of channels 0/1 of a block
+   * are neighbours (4 apart in the quad mapping) and run the same trip counts, so the swap
+   * always meets an active lane */
   auto finish = [&](int32_t y) -> int32_t {
     if (MS) {
-      const int32_t other = (int32_t)pair_swap((uint32_t)y);
+      const int32_t other = (int32_t)pair_swap<QUAD>((uint32_t)y);
       return c == 0 ? clip16(y + other) : clip16(other - y);
     }
     return y;
@@ -572,12 +733,17 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
 
   /* the first four samples are stored verbatim in the header - reference :386-391 */
   {
-    const int32_t y0 = finish(L.h3), y1 = finish(L.h2), y2 = finish(L.h1), y3 = finish(L.h0);
-    if (n > 0) dst[0] = (int16_t)y0;
-    if (n > 1) dst[ch] = (int16_t)y1;
-    if (n > 2) dst[2 * ch] = (int16_t)y2;
-    if (n > 3) dst[3 * ch] = (int16_t)y3;
+    const int32_t y0 = finish(H.h3), y1 = finish(H.h2), y2 = finish(H.h1), y3 = finish(H.h0);
+    if (writer) {
+      if (n > 0) dst[0] = (int16_t)y0;
+      if (n > 1) dst[ch] = (int16_t)y1;
+      if (n > 2) dst[2 * ch] = (int16_t)y2;
+      if (n > 3) dst[3 * ch] = (int16_t)y3;
+    }
   }
+  using S = std::conditional_t<QUAD, QuadLane, Lane>;
+  S L;
+  if constexpr (QUAD) L = to_quad(H, tap); else L = H;
 
   constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
   const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
@@ -612,7 +778,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       int32_t y[kChunk];
       decode_chunk16<BITS>(L, w, lds, y, finish);
       next.touch();
-      store_chunk_pcm<CHF>(op, y, c, ch);
+      if (writer) store_chunk_pcm<CHF, QUAD>(op, y, c, ch);
       op += (uint64_t)kChunk * ch;
     }
     done = full * kChunk;
@@ -632,7 +798,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       for (int k = 0; k < US; k++) {
         const int32_t y = finish(decode_step<BITS>(L, acc >> (32 - BITS), lds));
         acc <<= BITS;
-        if (i + k < coded) dst[(uint64_t)(kTaps + i + k) * ch] = (int16_t)y;
+        if (writer && i + k < coded) dst[(uint64_t)(kTaps + i + k) * ch] = (int16_t)y;
       }
     }
   }
@@ -772,7 +938,7 @@ __device__ __forceinline__ void store_be16(uint8_t *p, uint32_t v)
 
 /* block header of one channel - reference src/aad_encoder.c:619-655.  Drops the weight bits the
  * 16-bit header fields cannot carry from the lane's own state as well. */
-__device__ __forceinline__ void write_block_header(Lane &L, uint8_t *p)
+__device__ __forceinline__ void write_block_header(Lane &L, uint8_t *p, bool do_store)
 {
   auto wabs = [](int32_t w) { const int32_t m = w >> 31; return (int32_t)(((uint32_t)w ^ (uint32_t)m) - (uint32_t)m); };
   const int32_t maxabs = max(max(max(wabs(L.w0), wabs(L.w1)), max(wabs(L.w2), wabs(L.w3))), 0);
@@ -782,6 +948,7 @@ __device__ __forceinline__ void write_block_header(Lane &L, uint8_t *p)
   L.w1 &= mask;
   L.w2 &= mask;
   L.w3 &= mask;
+  if (!do_store) return;
   store_be16(p, ((((uint32_t)(L.idxb - kIdxBias)) << 4) & 0xFFFFu) | ((uint32_t)shift & 0xFu));
   store_be16(p + 2, (uint32_t)(L.w0 >> shift));
   store_be16(p + 4, (uint32_t)L.h0);
@@ -796,7 +963,7 @@ __device__ __forceinline__ void write_block_header(Lane &L, uint8_t *p)
 /* Write the packed codes of one 16-sample chunk.  w[]: big-endian code words of this lane's
  * channel.  up: first byte of the chunk's first unit of channel 0.  For stereo the two lanes of
  * a pair trade one word through DPP and each writes half of the interleaved bytes. */
-template <int BITS, int CHF>
+template <int BITS, int CHF, bool QUAD>
 __device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w, uint32_t c)
 {
   if (CHF == 1) {
@@ -813,13 +980,13 @@ __device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w
     }
   } else { /* stereo */
     if (BITS == 2) { /* out: a0 b0 a1 b1 | a2 b2 a3 b3 ; lane c writes dword c */
-      const uint32_t other = pair_swap(w[0]);
+      const uint32_t other = pair_swap<QUAD>(w[0]);
       const uint32_t A = c ? other : w[0], B = c ? w[0] : other; /* A = channel 0 word, B = channel 1 word */
       reinterpret_cast<U32 *>(up + 4 * c)->v = perm(A, B, c ? 0x00040105u : 0x02060307u);
     } else {
       /* lane 0 writes the first half (needs word 0 of both channels), lane 1 the second half */
       const uint32_t send = c ? w[0] : w[1], keep = c ? w[1] : w[0];
-      const uint32_t recv = pair_swap(send);
+      const uint32_t recv = pair_swap<QUAD>(send);
       const uint32_t A = c ? recv : keep, B = c ? keep : recv;
       if (BITS == 4) { /* a0 b0 a1 b1 | a2 b2 a3 b3 from A = a0 a1 a2 a3, B = b0 b1 b2 b3 (big-endian words) */
         u32x2 v;
@@ -838,32 +1005,39 @@ __device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w
  * Stream-parallel encode (reference src/aad_encoder.c:814-891 with EncodeBlock :565-727 and the
  * optional trial search :470-562 inlined).  lane = (stream, channel).
  */
-template <int BITS, int CHF, bool MS>
+template <int BITS, int CHF, bool MS, bool QUAD>
 __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
+  static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   stage_tables<BITS>(lds);
 
   const uint32_t ch = CHF ? CHF : a.channels;
-  const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (lane >= (uint64_t)a.num_streams * ch) return; /* whole stereo pairs leave together */
+  const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t lane = QUAD ? thread >> 2 : thread; /* index of the (stream, channel) recurrence */
+  const uint32_t tap = QUAD ? threadIdx.x & 3u : 0u;
+  const bool writer = tap == 0;                      /* quad: all four lanes hold the codes, one stores them */
+  if (lane >= (uint64_t)a.num_streams * ch) return; /* whole quads / stereo pairs leave together */
   const uint32_t s = (uint32_t)(lane / ch), c = (uint32_t)(lane % ch);
   const StreamDesc sd = a.streams[s];
   const SampleSource<MS> src = {a.pcm + sd.pcm_offset, ch, c};
   uint8_t *out = a.data + sd.data_offset;
   const uint32_t total = sd.num_samples, spb = a.samples_per_block;
 
-  Lane L = {0, 0, 0, 0, 0, 0, 0, 0, kIdxBias};
+  /* F: the complete per-channel state, the form block headers and the state records need;
+   * between block boundaries the quad mapping spreads it over four lanes (S) */
+  using S = std::conditional_t<QUAD, QuadLane, Lane>;
+  Lane F = {0, 0, 0, 0, 0, 0, 0, 0, kIdxBias};
   int32_t last_qd = 0;
   if (a.state) {
     const LaneStateRecord r = a.state[lane];
-    L = {r.weight[0], r.weight[1], r.weight[2], r.weight[3],
+    F = {r.weight[0], r.weight[1], r.weight[2], r.weight[3],
          r.history[0], r.history[1], r.history[2], r.history[3],
          min(max(r.stepsize_index, 0), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias};
     last_qd = r.quantize_error;
   }
 
-  if (c == 0) { /* file header - reference src/aad_encoder.c:190-214 */
+  if (c == 0 && writer) { /* file header - reference src/aad_encoder.c:190-214 */
     for (int i = 0; i < kFileHeaderBytes; i++) out[i] = a.header_template[i];
     out[14] = (uint8_t)(total >> 24);
     out[15] = (uint8_t)(total >> 16);
@@ -876,9 +1050,11 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
   uint64_t block_off = kFileHeaderBytes;
   for (uint64_t first = 0; first < total; first += spb, block_off += a.block_size) {
     const uint32_t n = total - first < spb ? (uint32_t)(total - first) : spb;
-    if (a.trials) search_best_lane<BITS>(L, src, first, n, spb, a.trials, lds);
-    seed_history(L, src, first, n);
-    write_block_header(L, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh);
+    if (!QUAD && a.trials) search_best_lane<BITS>(F, src, first, n, spb, a.trials, lds); /* host never pairs trials with QUAD */
+    seed_history(F, src, first, n);
+    write_block_header(F, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh, writer);
+    S L;
+    if constexpr (QUAD) L = to_quad(F, tap); else L = F;
     uint8_t *body = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch;
     const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
     uint32_t done = 0;
@@ -901,10 +1077,11 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
         if (k + 1 < full) xp += (uint64_t)kChunk * ch;
         next.load(xp, ch, c);
         uint32_t w[2] = {0, 0};
-        encode_chunk16<BITS>(L, x, lds, w, last_qd);
+        if constexpr (QUAD) encode_chunk16_quad<BITS>(L, x, lds, w, last_qd);
+        else encode_chunk16<BITS>(L, x, lds, w, last_qd);
         next.touch();
         if (CHF != 0) {
-          store_chunk_codes<BITS, (CHF ? CHF : 1)>(body + (uint64_t)k * kOutStride * ch, w, c);
+          if (writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD>(body + (uint64_t)k * kOutStride * ch, w, c);
         } else { /* any channel count: this lane's unit bytes one by one */
           uint8_t *up = body + (uint64_t)k * kOutStride * ch + (uint64_t)c * UB;
 #pragma unroll
@@ -929,16 +1106,19 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
         const int32_t x = i + k < coded ? src.at(first + kTaps + i + k) : 0;
         acc = (acc << BITS) | encode_step<BITS>(L, x, lds, last_qd);
       }
+      if (writer) {
 #pragma unroll
-      for (int k = 0; k < UB; k++) up[k] = (uint8_t)(acc >> (8 * (UB - 1 - k)));
+        for (int k = 0; k < UB; k++) up[k] = (uint8_t)(acc >> (8 * (UB - 1 - k)));
+      }
     }
+    if constexpr (QUAD) F = from_quad(L); else F = L;
   }
 
-  if (a.state) {
+  if (a.state && writer) {
     LaneStateRecord r;
-    r.weight[0] = L.w0; r.weight[1] = L.w1; r.weight[2] = L.w2; r.weight[3] = L.w3;
-    r.history[0] = L.h0; r.history[1] = L.h1; r.history[2] = L.h2; r.history[3] = L.h3;
-    r.stepsize_index = L.idxb - kIdxBias;
+    r.weight[0] = F.w0; r.weight[1] = F.w1; r.weight[2] = F.w2; r.weight[3] = F.w3;
+    r.history[0] = F.h0; r.history[1] = F.h1; r.history[2] = F.h2; r.history[3] = F.h3;
+    r.stepsize_index = F.idxb - kIdxBias;
     r.quantize_error = last_qd;
     a.state[lane] = r;
   }

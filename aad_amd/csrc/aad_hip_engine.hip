@@ -42,38 +42,6 @@ struct AADHipDecodePlan {
 
 namespace {
 
-/* Lanes are scarce in every BASELINE config (SURVEY.md section 7): while the batch has fewer
- * waves than the chip has SIMDs (256 CUs x 4) each wave gets a workgroup of its own so the
- * dispatcher spreads them over as many SIMDs as possible; big batches use 256-thread
- * workgroups so four waves share one LDS copy of the tables. */
-unsigned pick_workgroup(uint64_t lanes) { return lanes <= 64ull * 1024ull ? 64u : 256u; }
-
-template <int BITS>
-void launch_encode(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
-{
-  if (a.channels == 1)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false>), grid, block, 0, stream, a);
-  else if (a.channels == 2 && a.mid_side)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true>), grid, block, 0, stream, a);
-  else if (a.channels == 2)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false>), grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false>), grid, block, 0, stream, a);
-}
-
-template <int BITS>
-void launch_decode(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
-{
-  if (a.channels == 1)
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 1, false>), grid, block, 0, stream, a);
-  else if (a.channels == 2 && a.mid_side)
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true>), grid, block, 0, stream, a);
-  else if (a.channels == 2)
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false>), grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false>), grid, block, 0, stream, a);
-}
-
 bool hip_ok(AADHipContext *ctx, hipError_t e, const char *what)
 {
   if (e == hipSuccess) return true;
@@ -103,6 +71,76 @@ bool upload(AADHipContext *ctx, T **dst, const T *src, size_t count)
   /* pageable source: the copy is complete (staged) when this returns */
   return hip_ok(ctx, hipMemcpyAsync(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync") &&
          hip_ok(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+
+/* Lanes are scarce in every BASELINE config (SURVEY.md section 7): while the batch has fewer
+ * waves than the chip has SIMDs (256 CUs x 4) each wave gets a workgroup of its own so the
+ * dispatcher spreads them over as many SIMDs as possible; big batches use 256-thread
+ * workgroups so four waves share one LDS copy of the tables. */
+unsigned pick_workgroup(uint64_t threads) { return threads <= 64ull * 1024ull ? 64u : 256u; }
+
+/* Lane mapping: "quad" (four lanes per recurrence, fewer instructions per sample) while the
+ * batch cannot fill the chip anyway, "dense" (one lane per recurrence, fewest total
+ * instructions) beyond that.  The crossover is two quad-waves per SIMD.  AAD_HIP_MAPPING=dense|quad
+ * overrides the choice (the parity tests run both). */
+bool pick_quad(uint64_t recurrences, uint32_t channels, bool trials)
+{
+  if (channels > 2 || trials) return false;
+  const char *e = getenv("AAD_HIP_MAPPING");
+  if (e != nullptr && strcmp(e, "dense") == 0) return false;
+  if (e != nullptr && strcmp(e, "quad") == 0) return true;
+  return recurrences * 4 <= 2ull * 1024ull * 64ull;
+}
+
+template <int BITS, bool QUAD>
+void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
+{
+  if (a.channels == 1)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD>), grid, block, 0, stream, a);
+  else if (a.channels == 2 && a.mid_side)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD>), grid, block, 0, stream, a);
+  else if (a.channels == 2)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD>), grid, block, 0, stream, a);
+  else if constexpr (!QUAD)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false>), grid, block, 0, stream, a);
+}
+
+template <int BITS>
+void launch_encode(const aad::EncodeArgs &a, hipStream_t stream)
+{
+  const uint64_t lanes = (uint64_t)a.num_streams * a.channels;
+  const bool quad = pick_quad(lanes, a.channels, a.trials != 0);
+  const uint64_t threads = quad ? lanes * 4 : lanes;
+  const unsigned wg = pick_workgroup(threads);
+  const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
+  if (quad) launch_encode_mapped<BITS, true>(a, grid, block, stream);
+  else launch_encode_mapped<BITS, false>(a, grid, block, stream);
+}
+
+template <int BITS, bool QUAD>
+void launch_decode_mapped(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
+{
+  if (a.channels == 1)
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 1, false, QUAD>), grid, block, 0, stream, a);
+  else if (a.channels == 2 && a.mid_side)
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, QUAD>), grid, block, 0, stream, a);
+  else if (a.channels == 2)
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, QUAD>), grid, block, 0, stream, a);
+  else if constexpr (!QUAD)
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false, false>), grid, block, 0, stream, a);
+}
+
+template <int BITS>
+void launch_decode(const aad::DecodeArgs &a, hipStream_t stream)
+{
+  const uint64_t lanes = a.total_blocks * a.channels;
+  const bool quad = pick_quad(lanes, a.channels, false);
+  const uint64_t threads = quad ? lanes * 4 : lanes;
+  const unsigned wg = pick_workgroup(threads);
+  const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
+  if (quad) launch_decode_mapped<BITS, true>(a, grid, block, stream);
+  else launch_decode_mapped<BITS, false>(a, grid, block, stream);
 }
 
 } /* namespace */
@@ -247,13 +285,10 @@ AADApiResult AADHip_EncodePlanRun(struct AADHipEncodePlan *plan, const int16_t *
   a.pcm = device_pcm;
   a.data = device_data;
   a.state = reinterpret_cast<aad::LaneStateRecord *>(device_state);
-  const uint64_t lanes = (uint64_t)a.num_streams * a.channels;
-  const unsigned wg = pick_workgroup(lanes);
-  const dim3 grid((unsigned)((lanes + wg - 1) / wg)), block(wg);
   switch (a.bits) {
-    case 4: launch_encode<4>(a, grid, block, ctx->stream); break;
-    case 3: launch_encode<3>(a, grid, block, ctx->stream); break;
-    case 2: launch_encode<2>(a, grid, block, ctx->stream); break;
+    case 4: launch_encode<4>(a, ctx->stream); break;
+    case 3: launch_encode<3>(a, ctx->stream); break;
+    case 2: launch_encode<2>(a, ctx->stream); break;
     default: return AAD_APIRESULT_INVALID_FORMAT;
   }
   return hip_ok(ctx, hipGetLastError(), "encode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
@@ -342,13 +377,10 @@ AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *
   aad::DecodeArgs a = plan->args;
   a.data = device_data;
   a.pcm = device_pcm;
-  const uint64_t lanes = a.total_blocks * a.channels;
-  const unsigned wg = pick_workgroup(lanes);
-  const dim3 grid((unsigned)((lanes + wg - 1) / wg)), block(wg);
   switch (a.bits) {
-    case 4: launch_decode<4>(a, grid, block, ctx->stream); break;
-    case 3: launch_decode<3>(a, grid, block, ctx->stream); break;
-    case 2: launch_decode<2>(a, grid, block, ctx->stream); break;
+    case 4: launch_decode<4>(a, ctx->stream); break;
+    case 3: launch_decode<3>(a, ctx->stream); break;
+    case 2: launch_decode<2>(a, ctx->stream); break;
     default: return AAD_APIRESULT_INVALID_FORMAT;
   }
   return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;

@@ -30,6 +30,15 @@ def engine():
     e.close()
 
 
+@pytest.fixture(params=["dense", "quad"])
+def mapping(request):
+    """Both lane mappings of the kernels (one lane per recurrence / four lanes per recurrence):
+    the host picks by batch size, AAD_HIP_MAPPING forces one (read at every launch)."""
+    os.environ["AAD_HIP_MAPPING"] = request.param
+    yield request.param
+    os.environ.pop("AAD_HIP_MAPPING", None)
+
+
 @pytest.fixture(scope="module")
 def legacy():
     import torch  # noqa: F401
@@ -39,7 +48,7 @@ def legacy():
 # ---- (a) reference fixtures / golden hashes -----------------------------------------------
 
 @pytest.mark.parametrize("name", ["sin300Hz_mono", "sin300Hz"])
-def test_legacy_api_reproduces_reference_fixtures(legacy, name):
+def test_legacy_api_reproduces_reference_fixtures(legacy, name, mapping):
     """BASELINE config 1 through the GPU path: CLI defaults (4-bit, 1024, trials 2)."""
     pcm, rate = read_wav16(os.path.join(FIX, name + ".wav"))
     gold = open(os.path.join(FIX, name + ".aad"), "rb").read()
@@ -48,7 +57,7 @@ def test_legacy_api_reproduces_reference_fixtures(legacy, name):
     assert wav16_bytes(dec, hd.sampling_rate) == open(os.path.join(FIX, name + "_decoded.wav"), "rb").read()
 
 
-def test_manifest_cases_batched(engine):
+def test_manifest_cases_batched(engine, mapping):
     """Every golden case, grouped by parameter set into ragged batches (different lengths per stream)."""
     groups = {}
     for c in MANIFEST["cases"]:
@@ -65,7 +74,7 @@ def test_manifest_cases_batched(engine):
 
 
 @pytest.mark.parametrize("corpus", MANIFEST["corpora"], ids=lambda c: c["name"])
-def test_baseline_corpora_device_resident(engine, corpus):
+def test_baseline_corpora_device_resident(engine, corpus, mapping):
     """BASELINE configs 2/3/4(stereo)/5 shapes: device-resident uniform batches, hashed against the reference."""
     import torch
     pcm = synth_pcm(corpus["streams"], corpus["samples"], corpus["channels"], seed=corpus["seed"])
@@ -99,7 +108,7 @@ def test_eight_channel_lanes_equal_reference_mono(engine):
 
 @pytest.mark.parametrize("bits", [4, 3, 2])
 @pytest.mark.parametrize("channels", [1, 2, 3, 8])
-def test_ragged_batch_vs_oracle(engine, bits, channels):
+def test_ragged_batch_vs_oracle(engine, bits, channels, mapping):
     rng = np.random.default_rng(bits * 100 + channels)
     for trials, ms, mbs in ((0, False, 1024), (2, False, 256), (1, channels == 2, 1024), (0, channels == 2, 18 * channels + 24)):
         lens = [1, 2, 3, 4, 5, 6, 7, 12] + [int(v) for v in rng.integers(8, 5000, 40)]
@@ -113,7 +122,7 @@ def test_ragged_batch_vs_oracle(engine, bits, channels):
             assert np.array_equal(d, ob.decode(img)[0]), (i, lens[i])
 
 
-def test_state_carry_matches_oracle(engine):
+def test_state_carry_matches_oracle(engine, mapping):
     """encoder state in/out == the reference's reused-handle behaviour (src/aad_encoder.c:853-886)"""
     ch, streams = 2, 5
     state = np.zeros(streams * ch, dtype=LANE_STATE_DTYPE)
@@ -151,7 +160,7 @@ def test_legacy_handle_reuse_and_decode_block(legacy):
     assert np.array_equal(legacy.decode_block(hd, img[31:31 + bs], 10), full[:10])   # short buffer: decode until full
 
 
-def test_truncated_image_decodes_like_block_walk(engine):
+def test_truncated_image_decodes_like_block_walk(engine, mapping):
     pcm = synth_pcm(1, 5000, 2, seed=5)[0]
     img = ob.encode(pcm, 4, 1024)
     cut = img[: 31 + 1024 * 2 + 500]   # third block cut short: missing bytes read as zero
@@ -191,3 +200,22 @@ def test_plan_validation_errors(engine):
     with pytest.raises(ApiError) as e:
         engine.encode_plan(make_parameter(2, 4, 1024), d)
     assert e.value.code == R.INVALID_FORMAT
+
+
+def test_reference_cli_linked_against_this_library(tmp_path):
+    """the reference's own main.c / wav.c / option parser, compiled from
+    its sources in the build container and linked against libaad_hip.so instead of the reference
+    codec objects (oracle/_ref/aad_on_hip), reproduces the reference's fixtures with its default
+    options - `aad -e` / `aad -d` as in reference test/make_test_data.sh:4-7."""
+    import subprocess
+    cli = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "aad_on_hip")
+    if not os.path.exists(cli):
+        pytest.skip("oracle/_ref/aad_on_hip not built")
+    for name in ("sin300Hz_mono", "sin300Hz"):
+        out = tmp_path / (name + ".aad")
+        subprocess.run([cli, "-e", os.path.join(FIX, name + ".wav"), str(out)], check=True,
+                       stdout=subprocess.DEVNULL)
+        assert out.read_bytes() == open(os.path.join(FIX, name + ".aad"), "rb").read()
+        wav = tmp_path / (name + "_decoded.wav")
+        subprocess.run([cli, "-d", str(out), str(wav)], check=True, stdout=subprocess.DEVNULL)
+        assert wav.read_bytes() == open(os.path.join(FIX, name + "_decoded.wav"), "rb").read()
