@@ -520,6 +520,67 @@ __device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const ch
   });
 }
 
+/*
+ * Sixteen decoder steps for the quad mapping.  The prediction's two DPP butterfly adds each need
+ * two wait states after the instruction that wrote their operand (the compiler pads with
+ * s_nop 1, ~8 cycles apiece for a lone wave).  The decoder's step-index chain depends only on
+ * the codes, so it is run one sample further ahead than in decode_chunk16 and its instructions
+ * are placed exactly in those two gaps: index update after the product, slot address + lookups
+ * after the first butterfly add.  In flight per lane: the step sizes of samples j+1 and j+2 and
+ * the per-code records of samples j+1 .. j+3.
+ */
+template <int BITS, typename Finish>
+__device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, const uint32_t *w, const char *lds, int32_t *y, Finish finish)
+{
+  constexpr int cpw = Pack<BITS>::kCodesPerWord;
+  auto code_addr = [&](int j) -> uint32_t {
+    const int pos = Pack<BITS>::pos(j % cpw);
+    const uint32_t word = w[j / cpw];
+    return (pos >= 4 ? word >> (pos >= 4 ? pos - 4 : 0) : word << (4 - pos)) & (((1u << BITS) - 1u) << 4);
+  };
+  auto record = [&](int j) { return *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(j)); };
+  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(idxb)); };
+
+  uint32_t step0 = step_at(L.idxb); /* sample j */
+  u32x3 t0 = record(0), t1 = record(1), t2 = record(2);
+  L.idxb = clamp_idx(L.idxb + (int32_t)t0.z); /* from here on: the index of sample j+1 */
+  uint32_t step1 = step_at(L.idxb);
+  int32_t p = predict(L);
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int32_t qd = mad_i24((int32_t)step0, (int32_t)t0.x, (int32_t)t0.y) >> (BITS - 1);
+    const int32_t yy = clip16(qd + p);
+    lms_and_shift(L, qd, yy);
+    y[j] = finish(yy);
+    if (j + 1 < kChunk) {
+      uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
+      pin(s);
+      /* gap 1: index of sample j+2 (also the carry-out when j+2 == 16) */
+      int32_t idx2 = clamp_idx(L.idxb + (int32_t)t1.z);
+      pin(idx2);
+      s += quad_dpp<0xB1>(s);
+      pin(s);
+      /* gap 2: start the lookups that hang on it */
+      uint32_t step2 = step1;
+      u32x3 t3 = t2;
+      if (j + 2 < kChunk) step2 = step_at(idx2);
+      if (j + 3 < kChunk) t3 = record(j + 3 < kChunk ? j + 3 : j);
+      s += quad_dpp<0x4E>(s);
+      p = (int32_t)s >> 15;
+      pin(p);
+      step0 = step1;
+      step1 = step2;
+      t0 = t1;
+      t1 = t2;
+      t2 = t3;
+      L.idxb = idx2;
+    } else {
+      pin_weights(L);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 /* ---- per-lane byte shuffles ------------------------------------------------------------- */
 
 /* v_perm_b32: selector bytes 0-3 pick from `lo`, 4-7 from `hi`, 0x0c yields 0x00 */
@@ -776,7 +837,8 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       if (k + 1 < full) cp += kStride;
       next.load(cp);
       int32_t y[kChunk];
-      decode_chunk16<BITS>(L, w, lds, y, finish);
+      if constexpr (QUAD) decode_chunk16_quad<BITS>(L, w, lds, y, finish);
+      else decode_chunk16<BITS>(L, w, lds, y, finish);
       next.touch();
       if (writer) store_chunk_pcm<CHF, QUAD>(op, y, c, ch);
       op += (uint64_t)kChunk * ch;
