@@ -64,6 +64,13 @@ constexpr int kLdsStepOff = 0, kLdsHrOff = 1024, kLdsHsOff = 2048;
 constexpr int kLdsCodeOff = 3072;
 constexpr int kLdsDeltaOff = kLdsCodeOff + 16 * 16;
 constexpr int kLdsBytes = kLdsDeltaOff + 16;
+/* Quad kernels only: the same three values as 16-byte records {step, hr, hs, -}, addressed by
+ * idxb & 0xFF0 - one instruction less than slot_addr and one lookup instead of two.  A wave of
+ * the quad mapping holds just 16 distinct recurrences, so the 8-bank-group stride that made this
+ * layout an 8-way conflict with 64 recurrences per wave is harmless here. */
+constexpr int kLdsWideOff = (kLdsBytes + 15) & ~15;
+constexpr int kLdsBytesQuad = kLdsWideOff + AAD_STEP_TABLE_LEN * 16;
+__device__ __forceinline__ uint32_t wide_addr(int32_t idxb) { return (uint32_t)idxb & 0xFF0u; }
 
 /* byte offset of the step index's slot in the dword arrays */
 __device__ __forceinline__ uint32_t slot_addr(int32_t idxb) { return ((uint32_t)idxb >> 2) & 0x3FCu; }
@@ -91,6 +98,31 @@ struct StreamDesc {
   uint32_t num_samples;
   uint32_t reserved;
 };
+
+/* When every stream of a plan has the same length and the offsets form an arithmetic progression
+ * (the common batch shape, and the bench's), the kernels derive a lane's stream from its index
+ * instead of walking the table: no dependent global loads (a binary search costs ~10 of them,
+ * several microseconds for a lone wave) before the first useful byte is fetched. */
+struct UniformLayout {
+  uint64_t pcm_base, pcm_stride;   /* int16 elements */
+  uint64_t data_base, data_stride; /* bytes */
+  uint64_t data_size;
+  uint32_t num_samples;
+  uint32_t blocks_per_stream;      /* decode */
+  uint32_t enabled;
+  uint32_t reserved;
+};
+
+__device__ __forceinline__ StreamDesc uniform_stream(const UniformLayout &u, uint32_t s)
+{
+  StreamDesc d;
+  d.pcm_offset = u.pcm_base + (uint64_t)s * u.pcm_stride;
+  d.data_offset = u.data_base + (uint64_t)s * u.data_stride;
+  d.data_size = u.data_size;
+  d.num_samples = u.num_samples;
+  d.reserved = 0;
+  return d;
+}
 
 /* mirrors struct AADHipLaneState */
 struct LaneStateRecord {
@@ -129,15 +161,24 @@ struct Pack {
 };
 
 /* stage the tables into LDS; every thread of the workgroup must call this */
-template <int BITS>
+template <int BITS, bool QUAD>
 __device__ __forceinline__ void stage_tables(char *lds)
 {
   constexpr int kShift = BITS - 1;
   for (int i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) {
     const float hr = __uint_as_float(c_half_recip_bits[i]);
+    const float hs = hr * (float)(1 << kShift); /* exact power-of-two scaling */
     reinterpret_cast<uint32_t *>(lds + kLdsStepOff)[i] = c_step_table[i];
     reinterpret_cast<float *>(lds + kLdsHrOff)[i] = hr;
-    reinterpret_cast<float *>(lds + kLdsHsOff)[i] = hr * (float)(1 << kShift); /* exact power-of-two scaling */
+    reinterpret_cast<float *>(lds + kLdsHsOff)[i] = hs;
+    if (QUAD) {
+      u32x4 e;
+      e.x = c_step_table[i];
+      e.y = __float_as_uint(hr);
+      e.z = __float_as_uint(hs);
+      e.w = 0;
+      *reinterpret_cast<u32x4 *>(lds + kLdsWideOff + (i << 4)) = e;
+    }
   }
   const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
   if (threadIdx.x < (1 << BITS)) {
@@ -303,8 +344,10 @@ template <int BITS>
 __device__ __forceinline__ int32_t index_delta_arith(uint32_t mag)
 {
   if (BITS == 4) {
-    const int32_t t = (int32_t)(2u << mag);
-    return mag < 3 ? t - (int32_t)(mag + 20u) : t;
+    /* 2 << mag, minus {20, 21, 22, 0, 0, 0, 0, 0}[mag] picked by one v_perm_b32 byte lookup
+     * (selector bytes 1-3 = 0x0c give zero): no compare/select pair, no SGPR hazard */
+    const uint32_t corr = __builtin_amdgcn_perm(0u, 0x00161514u, mag | 0x0c0c0c00u);
+    return (int32_t)(2u << mag) - (int32_t)corr;
   } else if (BITS == 3) {
     return mag < 2 ? (int32_t)mag - 16 : (int32_t)(2u << (2u * mag));
   } else {
@@ -428,10 +471,7 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
 template <int BITS>
 __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out)
 {
-  uint32_t sa = slot_addr(L.idxb);
-  uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
-  float hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
-  float hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+  u32x3 e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb)); /* {step, hr, hs} */
   int32_t p = predict(L);
   int32_t d = x[0] - p;
   int32_t m = d >> 31;
@@ -439,15 +479,11 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, const int32_t *
   static_for<0, kChunk>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     /* A */
-    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), hs, hr), Pack<BITS>::kMagMax);
-    const uint32_t step_j = step;
+    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)),
+                             Pack<BITS>::kMagMax);
+    const uint32_t step_j = e.x;
     L.idxb = clamp_idx(L.idxb + index_delta_arith<BITS>(mag));
-    if (j + 1 < kChunk) {
-      sa = slot_addr(L.idxb);
-      step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
-      hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
-      hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
-    }
+    if (j + 1 < kChunk) e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
     __builtin_amdgcn_sched_barrier(0);
     /* B */
     const uint32_t m21 = (mag << 1) | 1u;
@@ -455,7 +491,8 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, const int32_t *
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
     uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
-    acc = (acc << BITS) | mag | ((uint32_t)m & Pack<BITS>::kSign);
+    const uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
+    acc = (acc << BITS) | code;                                     /* v_lshl_or_b32 */
     lms_and_shift(L, qd, y);
     if (j + 1 < kChunk) {
       p = predict(L);
@@ -539,7 +576,7 @@ __device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, const uint32_t 
     return (pos >= 4 ? word >> (pos >= 4 ? pos - 4 : 0) : word << (4 - pos)) & (((1u << BITS) - 1u) << 4);
   };
   auto record = [&](int j) { return *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(j)); };
-  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(idxb)); };
+  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsWideOff + wide_addr(idxb)); };
 
   uint32_t step0 = step_at(L.idxb); /* sample j */
   u32x3 t0 = record(0), t1 = record(1), t2 = record(2);
@@ -555,16 +592,19 @@ __device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, const uint32_t 
     if (j + 1 < kChunk) {
       uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
       pin(s);
-      /* gap 1: index of sample j+2 (also the carry-out when j+2 == 16) */
+      /* gap 1: index of sample j+2 (also the carry-out when j+2 == 16) and the record lookup of
+       * sample j+3.  The record is started BEFORE the step lookup below: LDS results return in
+       * order, so the wait for a step size at the top of a sample also covers the record whose
+       * delta is needed in the middle of the one before - one s_waitcnt per sample, not two. */
       int32_t idx2 = clamp_idx(L.idxb + (int32_t)t1.z);
+      u32x3 t3 = t2;
+      if (j + 3 < kChunk) t3 = record(j + 3 < kChunk ? j + 3 : j);
       pin(idx2);
       s += quad_dpp<0xB1>(s);
       pin(s);
-      /* gap 2: start the lookups that hang on it */
+      /* gap 2: start the step lookup that hangs on the new index */
       uint32_t step2 = step1;
-      u32x3 t3 = t2;
       if (j + 2 < kChunk) step2 = step_at(idx2);
-      if (j + 3 < kChunk) t3 = record(j + 3 < kChunk ? j + 3 : j);
       s += quad_dpp<0x4E>(s);
       p = (int32_t)s >> 15;
       pin(p);
@@ -609,6 +649,7 @@ struct DecodeArgs {
   uint32_t header_bytes; /* 31 (file image) or 0 (bare block) */
   uint32_t mid_side;
   uint32_t bits;
+  UniformLayout uni;
 };
 
 /* last stream whose first block index is <= g */
@@ -736,8 +777,8 @@ template <int BITS, int CHF, bool MS, bool QUAD>
 __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-  stage_tables<BITS>(lds);
+  __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
+  stage_tables<BITS, QUAD>(lds);
 
   const uint32_t ch = CHF ? CHF : a.channels;
   const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -748,9 +789,18 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
   const uint64_t g = active ? lane / ch : 0;
   const uint32_t c = active ? (uint32_t)(lane % ch) : 0;
 
-  const uint32_t s = find_stream(a.block_prefix, a.num_streams, g);
-  const StreamDesc sd = a.streams[s];
-  const uint64_t b = g - a.block_prefix[s];
+  uint32_t s;
+  StreamDesc sd;
+  uint64_t b;
+  if (a.uni.enabled) { /* wave-uniform branch */
+    s = (uint32_t)g / a.uni.blocks_per_stream; /* the host only enables this below 2^32 blocks */
+    b = (uint32_t)g - s * a.uni.blocks_per_stream;
+    sd = uniform_stream(a.uni, s);
+  } else {
+    s = find_stream(a.block_prefix, a.num_streams, g);
+    sd = a.streams[s];
+    b = g - a.block_prefix[s];
+  }
   const uint64_t first = b * a.samples_per_block;
   uint32_t n = 0;
   if (active && first < sd.num_samples) {
@@ -880,6 +930,7 @@ struct EncodeArgs {
   uint32_t mid_side;
   uint32_t trials;
   uint32_t bits;
+  UniformLayout uni;
   uint8_t header_template[32]; /* 31-byte file header with num_samples = 0 */
 };
 
@@ -1071,8 +1122,8 @@ template <int BITS, int CHF, bool MS, bool QUAD>
 __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-  stage_tables<BITS>(lds);
+  __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
+  stage_tables<BITS, QUAD>(lds);
 
   const uint32_t ch = CHF ? CHF : a.channels;
   const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1081,7 +1132,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
   const bool writer = tap == 0;                      /* quad: all four lanes hold the codes, one stores them */
   if (lane >= (uint64_t)a.num_streams * ch) return; /* whole quads / stereo pairs leave together */
   const uint32_t s = (uint32_t)(lane / ch), c = (uint32_t)(lane % ch);
-  const StreamDesc sd = a.streams[s];
+  const StreamDesc sd = a.uni.enabled ? uniform_stream(a.uni, s) : a.streams[s];
   const SampleSource<MS> src = {a.pcm + sd.pcm_offset, ch, c};
   uint8_t *out = a.data + sd.data_offset;
   const uint32_t total = sd.num_samples, spb = a.samples_per_block;

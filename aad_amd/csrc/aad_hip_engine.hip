@@ -63,6 +63,27 @@ struct DeviceGuard { /* select the context's device for the calling thread, rest
   }
 };
 
+/* arithmetic-progression stream tables get the table-free kernel path (aad::UniformLayout) */
+aad::UniformLayout detect_uniform(uint32_t n, const AADHipStreamDesc *t)
+{
+  aad::UniformLayout u;
+  memset(&u, 0, sizeof(u));
+  if (n == 0) return u;
+  const uint64_t ps = n > 1 ? t[1].pcm_offset - t[0].pcm_offset : 0, ds = n > 1 ? t[1].data_offset - t[0].data_offset : 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (t[i].num_samples != t[0].num_samples || t[i].data_size != t[0].data_size) return u;
+    if (t[i].pcm_offset != t[0].pcm_offset + (uint64_t)i * ps || t[i].data_offset != t[0].data_offset + (uint64_t)i * ds) return u;
+  }
+  u.pcm_base = t[0].pcm_offset;
+  u.pcm_stride = ps;
+  u.data_base = t[0].data_offset;
+  u.data_stride = ds;
+  u.data_size = t[0].data_size;
+  u.num_samples = t[0].num_samples;
+  u.enabled = 1;
+  return u;
+}
+
 template <typename T>
 bool upload(AADHipContext *ctx, T **dst, const T *src, size_t count)
 {
@@ -255,6 +276,7 @@ AADApiResult AADHip_EncodePlanCreate(struct AADHipContext *ctx, const struct AAD
   p->args.samples_per_block = h.num_samples_per_block;
   p->args.mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
   p->args.trials = parameter->num_encode_trials;
+  p->args.uni = detect_uniform(num_streams, streams);
   h.num_samples = 0;
   AADFormat_PutHeader(&h, p->args.header_template);
   p->args.bits = h.bits_per_sample;
@@ -349,6 +371,11 @@ AADApiResult AADHip_DecodePlanCreate(struct AADHipContext *ctx, const struct AAD
   p->args.block_size = h.block_size;
   p->args.samples_per_block = h.num_samples_per_block;
   p->args.header_bytes = head;
+  p->args.uni = detect_uniform(num_streams, streams);
+  if (p->args.uni.enabled) {
+    p->args.uni.blocks_per_stream = (uint32_t)(prefix.size() > 1 ? prefix[1] - prefix[0] : 0);
+    if (p->args.uni.blocks_per_stream == 0 || blocks >= 0xFFFFFFFFull) p->args.uni.enabled = 0;
+  }
   p->args.mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
   p->args.bits = h.bits_per_sample;
   *plan = p;

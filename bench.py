@@ -33,6 +33,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def measured_traffic(kernel_key, streams, samples):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_hbm_traffic.json, made by tools/hbm_traffic.py from separate FETCH_SIZE /
+    WRITE_SIZE runs of this same command line).  None when the file does not cover this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    if t.get("streams") != streams or t.get("samples_per_channel") != samples:
+        return None
+    k = t.get("kernels", {}).get(kernel_key)
+    return k.get("hbm_bytes_per_launch") if k else None
+
+
 def algorithmic_bytes_per_sample(channels, block_size, spb):
     """2 (int16 PCM) + block_size / (samples_per_block * channels)"""
     return 2.0 + block_size / float(spb * channels)
@@ -166,6 +181,7 @@ def main():
     ap.add_argument("--trials", type=int, default=0, help="num_encode_trials (reference CLI default is 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true")
+    ap.add_argument("--saturated-streams", type=int, default=262144)
     args = ap.parse_args()
 
     import numpy as np
@@ -220,7 +236,8 @@ def main():
             "workload": "BASELINE configs[1]+[2]: %d independent 48 kHz stereo 4-bit streams x %d block(s) "
                         "(%d samples/ch) per GPU, encode then decode, device-resident" % (args.streams, args.blocks, samples),
             "streams_per_gpu": args.streams, "samples_per_channel": samples, "channels": ch, "bits_per_sample": bits,
-            "max_block_size": mbs, "num_encode_trials": args.trials, "lanes_encode": args.streams * ch,
+            "max_block_size": mbs, "num_encode_trials": args.trials, "lane_mapping": os.environ.get("AAD_HIP_MAPPING", "auto (quad for this batch size)"),
+            "lanes_encode": args.streams * ch,
             "lanes_decode": args.streams * args.blocks * ch,
             "value_counts": "samples encoded + samples decoded",
         },
@@ -229,7 +246,8 @@ def main():
         "roofline": {
             "kernel": "aad::encode_streams_kernel<4>",
             "bound": "hbm", "achieved": round(enc_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(enc_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+            "frac": round(enc_gbs / HBM_PEAK_GBS, 6), "traffic": measured_traffic("encode", args.streams, samples),
+            "algorithmic_bytes_per_launch": int(round(n_step * bps)),
             "bytes_per_sample": round(bps, 4), "samples_per_launch": n_step,
             "kernel_ms": round(m["enc_ms"], 5),
             "decode_kernel": {"kernel": "aad::decode_blocks_kernel<4>", "achieved": round(dec_gbs, 3),
@@ -238,10 +256,11 @@ def main():
     }
 
     if not args.no_saturated and world == 1:
-        big_streams = 65536
+        big_streams = args.saturated_streams  # 262144 stereo streams = 8192 waves = 8 per SIMD (dense mapping)
         reps = -(-big_streams // args.streams)
         big = pcm.repeat((reps, 1, 1))[:big_streams].contiguous()
-        ms = measure(engine, torch, dist, big, param, 10, 2, 1)
+        ms = measure(engine, torch, dist, big, param, 5, 1, 1)
+        del big
         nb = big_streams * samples * ch
         line["saturated"] = {
             "workload": "%d stereo streams x %d samples/ch per launch (the step batch tiled)" % (big_streams, samples),
