@@ -430,7 +430,9 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     const int32_t y = clip16(qd + p);
     lms_first(L, qd);
     uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
-    acc = (acc << BITS) | mag | ((uint32_t)m & Pack<BITS>::kSign);
+    uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
+    pin(code);
+    acc = (acc << BITS) | code;                               /* v_lshl_or_b32 */
     pin_weights(L);
     pin(acc);
     __builtin_amdgcn_sched_barrier(0);
@@ -468,14 +470,31 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
  *   A  quantise, delta, new step index; start the lookup of the next sample's step record
  *   B  dequantise, reconstruct, LMS, history shift, pack the code, predict + difference of the next sample
  */
+struct EncodeCarry {
+  u32x3 e;         /* {step, hr, hs} of the coming sample */
+  int32_t p, d, m; /* its prediction, difference and sign mask */
+  float f;         /* (float)d */
+};
+
 template <int BITS>
-__device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out)
+__device__ __forceinline__ void encode_prime_quad(QuadLane &L, EncodeCarry &C, int32_t x0, const char *lds)
 {
-  u32x3 e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb)); /* {step, hr, hs} */
-  int32_t p = predict(L);
-  int32_t d = x[0] - p;
-  int32_t m = d >> 31;
-  float f = (float)d;
+  C.e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
+  C.p = predict(L);
+  C.d = x0 - C.p;
+  C.m = C.d >> 31;
+  C.f = (float)C.d;
+}
+
+/* x: this chunk's 16 samples, xn0: the first sample of the next chunk (the pipeline is carried
+ * from chunk to chunk like the decoder's, see DecodeCarry) */
+template <int BITS>
+__device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C, const int32_t *x, int32_t xn0,
+                                                    const char *lds, uint32_t *w, int32_t &qd_out)
+{
+  u32x3 e = C.e;
+  int32_t p = C.p, d = C.d, m = C.m;
+  float f = C.f;
   static_for<0, kChunk>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     /* A */
@@ -483,31 +502,41 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, const int32_t *
                              Pack<BITS>::kMagMax);
     const uint32_t step_j = e.x;
     L.idxb = clamp_idx(L.idxb + index_delta_arith<BITS>(mag));
-    if (j + 1 < kChunk) e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
+    e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
     __builtin_amdgcn_sched_barrier(0);
     /* B */
     const uint32_t m21 = (mag << 1) | 1u;
     const int32_t q = (int32_t)(__umul24(step_j, m21) >> (BITS - 1));
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
-    uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
-    const uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
-    acc = (acc << BITS) | code;                                     /* v_lshl_or_b32 */
     lms_and_shift(L, qd, y);
-    if (j + 1 < kChunk) {
-      p = predict(L);
-      d = x[j + 1] - p;
-      m = d >> 31;
-      f = (float)d;
-      pin(m);
-      pin(f);
-    } else {
-      qd_out = qd;
-      pin_weights(L);
-    }
+    /* prediction of the next sample, with the two instructions that pack this sample's code
+     * placed in the wait states its DPP adds need (see decode_chunk16_quad) */
+    uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
+    pin(s);
+    uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
+    uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
+    pin(code);
+    s += quad_dpp<0xB1>(s);
+    pin(s);
+    acc = (acc << BITS) | code; /* v_lshl_or_b32 */
     pin(acc);
+    s += quad_dpp<0x4E>(s);
+    p = (int32_t)s >> 15;
+    d = (j + 1 < kChunk ? x[j + 1 < kChunk ? j + 1 : j] : xn0) - p;
+    m = d >> 31;
+    f = (float)d;
+    pin(m);
+    pin(f);
+    pin(acc);
+    if (j + 1 == kChunk) qd_out = qd;
     __builtin_amdgcn_sched_barrier(0);
   });
+  C.e = e;
+  C.p = p;
+  C.d = d;
+  C.m = m;
+  C.f = f;
 }
 
 /*
@@ -559,66 +588,95 @@ __device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const ch
 
 /*
  * Sixteen decoder steps for the quad mapping.  The prediction's two DPP butterfly adds each need
- * two wait states after the instruction that wrote their operand (the compiler pads with
- * s_nop 1, ~8 cycles apiece for a lone wave).  The decoder's step-index chain depends only on
- * the codes, so it is run one sample further ahead than in decode_chunk16 and its instructions
- * are placed exactly in those two gaps: index update after the product, slot address + lookups
- * after the first butterfly add.  In flight per lane: the step sizes of samples j+1 and j+2 and
- * the per-code records of samples j+1 .. j+3.
+ * wait states after the instruction that wrote their operand (the compiler pads with s_nop, ~4-8
+ * cycles apiece for a lone wave).  The decoder's step-index chain depends only on the codes, so
+ * it is run one sample further ahead than in decode_chunk16 and its instructions are placed
+ * exactly in those gaps: index update + record lookup after the product, slot address + step
+ * lookup after the first butterfly add.  In flight per lane: the step sizes of samples j+1 and
+ * j+2 and the per-code records of samples j+1 .. j+3.
+ *
+ * The pipeline is carried from chunk to chunk (DecodeCarry) instead of being re-primed every 16
+ * samples - a re-prime costs two exposed LDS round trips and a DPP reduction, ~170 cycles.  For
+ * that the last three samples of a chunk look their records up in the NEXT chunk's code words
+ * (wn), which the kernel unpacks one chunk early.
  */
-template <int BITS, typename Finish>
-__device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, const uint32_t *w, const char *lds, int32_t *y, Finish finish)
+struct DecodeCarry {
+  uint32_t step0, step1; /* step sizes of samples j, j+1 */
+  u32x3 t0, t1, t2;      /* per-code records of samples j, j+1, j+2 */
+  int32_t p;             /* prediction for sample j */
+  int32_t idx_next;      /* step index (biased) of the first sample after the chunk just finished */
+};
+
+template <int BITS>
+__device__ __forceinline__ uint32_t chunk_code_addr(const uint32_t *w, const uint32_t *wn, int j)
 {
   constexpr int cpw = Pack<BITS>::kCodesPerWord;
-  auto code_addr = [&](int j) -> uint32_t {
-    const int pos = Pack<BITS>::pos(j % cpw);
-    const uint32_t word = w[j / cpw];
-    return (pos >= 4 ? word >> (pos >= 4 ? pos - 4 : 0) : word << (4 - pos)) & (((1u << BITS) - 1u) << 4);
-  };
-  auto record = [&](int j) { return *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(j)); };
-  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsWideOff + wide_addr(idxb)); };
+  const uint32_t word = j < kChunk ? w[j / cpw] : wn[(j - kChunk) / cpw];
+  const int pos = Pack<BITS>::pos((j % kChunk) % cpw);
+  return (pos >= 4 ? word >> (pos >= 4 ? pos - 4 : 0) : word << (4 - pos)) & (((1u << BITS) - 1u) << 4);
+}
 
-  uint32_t step0 = step_at(L.idxb); /* sample j */
-  u32x3 t0 = record(0), t1 = record(1), t2 = record(2);
-  L.idxb = clamp_idx(L.idxb + (int32_t)t0.z); /* from here on: the index of sample j+1 */
-  uint32_t step1 = step_at(L.idxb);
-  int32_t p = predict(L);
+template <int BITS>
+__device__ __forceinline__ void decode_prime_quad(QuadLane &L, DecodeCarry &C, const uint32_t *w, const char *lds)
+{
+  auto record = [&](int j) { return *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + chunk_code_addr<BITS>(w, w, j)); };
+  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsWideOff + wide_addr(idxb)); };
+  C.step0 = step_at(L.idxb);
+  C.t0 = record(0);
+  C.t1 = record(1);
+  C.t2 = record(2);
+  L.idxb = clamp_idx(L.idxb + (int32_t)C.t0.z); /* from here on L.idxb runs one sample ahead */
+  C.step1 = step_at(L.idxb);
+  C.p = predict(L);
+  C.idx_next = L.idxb;
+}
+
+template <int BITS, typename Finish>
+__device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, DecodeCarry &C, const uint32_t *w, const uint32_t *wn,
+                                                    const char *lds, int32_t *y, Finish finish)
+{
+  auto record = [&](int j) { return *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + chunk_code_addr<BITS>(w, wn, j)); };
+  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsWideOff + wide_addr(idxb)); };
+  uint32_t step0 = C.step0, step1 = C.step1;
+  u32x3 t0 = C.t0, t1 = C.t1, t2 = C.t2;
+  int32_t p = C.p;
   static_for<0, kChunk>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const int32_t qd = mad_i24((int32_t)step0, (int32_t)t0.x, (int32_t)t0.y) >> (BITS - 1);
     const int32_t yy = clip16(qd + p);
     lms_and_shift(L, qd, yy);
     y[j] = finish(yy);
-    if (j + 1 < kChunk) {
-      uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
-      pin(s);
-      /* gap 1: index of sample j+2 (also the carry-out when j+2 == 16) and the record lookup of
-       * sample j+3.  The record is started BEFORE the step lookup below: LDS results return in
-       * order, so the wait for a step size at the top of a sample also covers the record whose
-       * delta is needed in the middle of the one before - one s_waitcnt per sample, not two. */
-      int32_t idx2 = clamp_idx(L.idxb + (int32_t)t1.z);
-      u32x3 t3 = t2;
-      if (j + 3 < kChunk) t3 = record(j + 3 < kChunk ? j + 3 : j);
-      pin(idx2);
-      s += quad_dpp<0xB1>(s);
-      pin(s);
-      /* gap 2: start the step lookup that hangs on the new index */
-      uint32_t step2 = step1;
-      if (j + 2 < kChunk) step2 = step_at(idx2);
-      s += quad_dpp<0x4E>(s);
-      p = (int32_t)s >> 15;
-      pin(p);
-      step0 = step1;
-      step1 = step2;
-      t0 = t1;
-      t1 = t2;
-      t2 = t3;
-      L.idxb = idx2;
-    } else {
-      pin_weights(L);
-    }
+    uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
+    pin(s);
+    /* gap 1: index of sample j+2 and the record lookup of sample j+3.  The record is started
+     * BEFORE the step lookup below: LDS results return in order, so the wait for a step size at
+     * the top of a sample also covers the record whose delta is needed in the middle of the one
+     * before - one s_waitcnt per sample, not two. */
+    int32_t idx2 = clamp_idx(L.idxb + (int32_t)t1.z);
+    const u32x3 t3 = record(j + 3);
+    pin(idx2);
+    s += quad_dpp<0xB1>(s);
+    pin(s);
+    /* gap 2: start the step lookup that hangs on the new index */
+    const uint32_t step2 = step_at(idx2);
+    s += quad_dpp<0x4E>(s);
+    p = (int32_t)s >> 15;
+    pin(p);
+    if (j == kChunk - 2) C.idx_next = idx2; /* index of sample 16: what a non-pipelined continuation needs */
+    step0 = step1;
+    step1 = step2;
+    t0 = t1;
+    t1 = t2;
+    t2 = t3;
+    L.idxb = idx2;
     __builtin_amdgcn_sched_barrier(0);
   });
+  C.step0 = step0;
+  C.step1 = step1;
+  C.t0 = t0;
+  C.t1 = t1;
+  C.t2 = t2;
+  C.p = p;
 }
 
 /* ---- per-lane byte shuffles ------------------------------------------------------------- */
@@ -628,9 +686,15 @@ __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
 
 /* value of the neighbouring lane (lane ^ 1): the other channel of a stereo pair */
 template <bool QUAD>
-__device__ __forceinline__ uint32_t pair_swap(uint32_t v)
+__device__ __forceinline__ uint32_t pair_swap(uint32_t v, uint32_t c)
 {
-  if (QUAD) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F); /* lane ^ 4: the same tap of the other channel's quad */
+  if (QUAD) {
+    /* lane ^ 4: the same tap of the other channel's quad.  Two DPP row shifts and a select
+     * (~13 cycles) rather than ds_swizzle (an LDS round trip, ~64 cycles, on the store path) */
+    const uint32_t from_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104 /* row_shl:4 */, 0xF, 0xF, true);
+    const uint32_t from_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    return c ? from_lo : from_hi;
+  }
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
 }
 
@@ -754,7 +818,7 @@ __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *
       const uint32_t p1 = perm((uint32_t)y[8 * h + 3], (uint32_t)y[8 * h + 2], 0x05040100);
       const uint32_t p2 = perm((uint32_t)y[8 * h + 5], (uint32_t)y[8 * h + 4], 0x05040100);
       const uint32_t p3 = perm((uint32_t)y[8 * h + 7], (uint32_t)y[8 * h + 6], 0x05040100);
-      const uint32_t ra = pair_swap<QUAD>(c ? p0 : p2), rb = pair_swap<QUAD>(c ? p1 : p3);
+      const uint32_t ra = pair_swap<QUAD>(c ? p0 : p2, c), rb = pair_swap<QUAD>(c ? p1 : p3, c);
       const uint32_t ka = c ? p2 : p0, kb = c ? p3 : p1;
       u32x4 v;
       v.x = perm(ka, ra, sel_lo);
@@ -836,7 +900,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
    * always meets an active lane */
   auto finish = [&](int32_t y) -> int32_t {
     if (MS) {
-      const int32_t other = (int32_t)pair_swap<QUAD>((uint32_t)y);
+      const int32_t other = (int32_t)pair_swap<QUAD>((uint32_t)y, c);
       return c == 0 ? clip16(y + other) : clip16(other - y);
     }
     return y;
@@ -878,20 +942,47 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
     next.r[0] = next.r[1] = next.r[2] = next.r[3] = 0;
     if (full) next.load(cp);
     next.touch();
-    for (uint32_t k = 0; k < full; k++) {
-      uint32_t w[2] = {0, 0};
-      next.unpack(c, w);
-      /* prefetch the next chunk (the last iteration re-reads its own: an unconditional load lands
-       * straight in `next`'s registers, a conditional one would be copied - and waited for - at once);
-       * it is consumed (touch) only after this chunk's arithmetic */
-      if (k + 1 < full) cp += kStride;
-      next.load(cp);
-      int32_t y[kChunk];
-      if constexpr (QUAD) decode_chunk16_quad<BITS>(L, w, lds, y, finish);
-      else decode_chunk16<BITS>(L, w, lds, y, finish);
-      next.touch();
-      if (writer) store_chunk_pcm<CHF, QUAD>(op, y, c, ch);
-      op += (uint64_t)kChunk * ch;
+    if constexpr (QUAD) {
+      /* pipeline carried across chunks: the code words of chunk k+1 are unpacked one chunk early */
+      uint32_t w[2] = {0, 0}, wn[2] = {0, 0};
+      DecodeCarry C;
+      if (full) {
+        next.unpack(c, w);
+        if (full > 1) cp += kStride;
+        next.load(cp);
+        next.touch();
+        next.unpack(c, wn);
+        decode_prime_quad<BITS>(L, C, w, lds);
+      }
+      for (uint32_t k = 0; k < full; k++) {
+        /* prefetch chunk k+2 (clamped to the last full chunk), consumed after this chunk's arithmetic */
+        if (k + 2 < full) cp += kStride;
+        next.load(cp);
+        int32_t y[kChunk];
+        decode_chunk16_quad<BITS>(L, C, w, wn, lds, y, finish);
+        next.touch();
+        w[0] = wn[0];
+        w[1] = wn[1];
+        next.unpack(c, wn);
+        if (writer) store_chunk_pcm<CHF, QUAD>(op, y, c, ch);
+        op += (uint64_t)kChunk * ch;
+      }
+      if (full) L.idxb = C.idx_next; /* drop the run-ahead: the tail below is not pipelined */
+    } else {
+      for (uint32_t k = 0; k < full; k++) {
+        uint32_t w[2] = {0, 0};
+        next.unpack(c, w);
+        /* prefetch the next chunk (the last iteration re-reads its own: an unconditional load lands
+         * straight in `next`'s registers, a conditional one would be copied - and waited for - at once);
+         * it is consumed (touch) only after this chunk's arithmetic */
+        if (k + 1 < full) cp += kStride;
+        next.load(cp);
+        int32_t y[kChunk];
+        decode_chunk16<BITS>(L, w, lds, y, finish);
+        next.touch();
+        if (writer) store_chunk_pcm<CHF, QUAD>(op, y, c, ch);
+        op += (uint64_t)kChunk * ch;
+      }
     }
     done = full * kChunk;
   }
@@ -1093,13 +1184,13 @@ __device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w
     }
   } else { /* stereo */
     if (BITS == 2) { /* out: a0 b0 a1 b1 | a2 b2 a3 b3 ; lane c writes dword c */
-      const uint32_t other = pair_swap<QUAD>(w[0]);
+      const uint32_t other = pair_swap<QUAD>(w[0], c);
       const uint32_t A = c ? other : w[0], B = c ? w[0] : other; /* A = channel 0 word, B = channel 1 word */
       reinterpret_cast<U32 *>(up + 4 * c)->v = perm(A, B, c ? 0x00040105u : 0x02060307u);
     } else {
       /* lane 0 writes the first half (needs word 0 of both channels), lane 1 the second half */
       const uint32_t send = c ? w[0] : w[1], keep = c ? w[1] : w[0];
-      const uint32_t recv = pair_swap<QUAD>(send);
+      const uint32_t recv = pair_swap<QUAD>(send, c);
       const uint32_t A = c ? recv : keep, B = c ? keep : recv;
       if (BITS == 4) { /* a0 b0 a1 b1 | a2 b2 a3 b3 from A = a0 a1 a2 a3, B = b0 b1 b2 b3 (big-endian words) */
         u32x2 v;
@@ -1182,6 +1273,34 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
       for (auto &v : next.d) v = 0;
       if (full) next.load(xp, ch, c);
       next.touch();
+      if constexpr (QUAD) {
+        /* pipeline carried across chunks: chunk k+1's samples are extracted one chunk early */
+        int32_t x[kChunk], xn[kChunk];
+        EncodeCarry C;
+        if (full) {
+#pragma unroll
+          for (int j = 0; j < kChunk; j++) x[j] = next.get(j, c);
+          if (full > 1) xp += (uint64_t)kChunk * ch;
+          next.load(xp, ch, c);
+          next.touch();
+#pragma unroll
+          for (int j = 0; j < kChunk; j++) xn[j] = next.get(j, c);
+          encode_prime_quad<BITS>(L, C, x[0], lds);
+        }
+        for (uint32_t k = 0; k < full; k++) {
+          if (k + 2 < full) xp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
+          next.load(xp, ch, c);
+          uint32_t w[2] = {0, 0};
+          encode_chunk16_quad<BITS>(L, C, x, xn[0], lds, w, last_qd);
+          next.touch();
+#pragma unroll
+          for (int j = 0; j < kChunk; j++) {
+            x[j] = xn[j];
+            xn[j] = next.get(j, c);
+          }
+          if (writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD>(body + (uint64_t)k * kOutStride * ch, w, c);
+        }
+      } else {
       for (uint32_t k = 0; k < full; k++) {
         int32_t x[kChunk];
 #pragma unroll
@@ -1190,11 +1309,10 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
         if (k + 1 < full) xp += (uint64_t)kChunk * ch;
         next.load(xp, ch, c);
         uint32_t w[2] = {0, 0};
-        if constexpr (QUAD) encode_chunk16_quad<BITS>(L, x, lds, w, last_qd);
-        else encode_chunk16<BITS>(L, x, lds, w, last_qd);
+        encode_chunk16<BITS>(L, x, lds, w, last_qd);
         next.touch();
         if (CHF != 0) {
-          if (writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD>(body + (uint64_t)k * kOutStride * ch, w, c);
+          store_chunk_codes<BITS, (CHF ? CHF : 1), false>(body + (uint64_t)k * kOutStride * ch, w, c);
         } else { /* any channel count: this lane's unit bytes one by one */
           uint8_t *up = body + (uint64_t)k * kOutStride * ch + (uint64_t)c * UB;
 #pragma unroll
@@ -1206,6 +1324,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
             for (int q = 0; q < UB; q++) up[(uint64_t)u * unit_stride + q] = (uint8_t)(unit >> (8 * (UB - 1 - q)));
           }
         }
+      }
       }
       done = full * kChunk;
     }
