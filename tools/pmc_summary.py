@@ -41,7 +41,7 @@ def main():
                 if n in c:
                     print("   -> %-20s %5.1f %% of wave cycles" % (n, 100.0 * c[n] / c["SQ_WAVE_CYCLES"]))
         if "SQ_INSTS_VALU" in c:
-            lanes_waves = 32.0
+            lanes_waves = c.get("SQ_WAVES", 32.0)
             print("   -> VALU/wave/sample %.2f (assuming %d waves, %.0f samples per lane)" % (c["SQ_INSTS_VALU"] / lanes_waves / per_lane, lanes_waves, per_lane))
 
 
