@@ -406,8 +406,14 @@ __device__ __forceinline__ int32_t decode_step(S &L, uint32_t code, const char *
  *   D  LMS taps 2-3, history shift, predict + difference of the NEXT sample (hides the record lookup)
  * Same arithmetic as encode_step, instruction for instruction.
  */
-template <int BITS, typename S>
-__device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out)
+/* squared dequantised difference as the reference accumulates it (src/aad_encoder.c:461): the
+ * product wraps in int32 before it is widened (SURVEY.md finding 5) */
+__device__ __forceinline__ int64_t wrapped_square(int32_t qd) { return (int64_t)(int32_t)((uint32_t)qd * (uint32_t)qd); }
+
+/* EMIT: pack the codes into w[] (the real encode pass); otherwise add the wrapped squares of the
+ * dequantised differences to sq (an RMSE pass of the trial search - same recurrence, no output) */
+template <int BITS, bool EMIT, typename S>
+__device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq)
 {
   uint32_t sa = slot_addr(L.idxb);
   uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
@@ -429,12 +435,16 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
     lms_first(L, qd);
-    uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
-    uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
-    pin(code);
-    acc = (acc << BITS) | code;                               /* v_lshl_or_b32 */
+    if (EMIT) {
+      uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
+      uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
+      pin(code);
+      acc = (acc << BITS) | code;                               /* v_lshl_or_b32 */
+      pin(acc);
+    } else {
+      sq += wrapped_square(qd);
+    }
     pin_weights(L);
-    pin(acc);
     __builtin_amdgcn_sched_barrier(0);
     /* C */
     L.idxb = clamp_idx(L.idxb + delta);
@@ -488,9 +498,9 @@ __device__ __forceinline__ void encode_prime_quad(QuadLane &L, EncodeCarry &C, i
 
 /* x: this chunk's 16 samples, xn0: the first sample of the next chunk (the pipeline is carried
  * from chunk to chunk like the decoder's, see DecodeCarry) */
-template <int BITS>
+template <int BITS, bool EMIT>
 __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C, const int32_t *x, int32_t xn0,
-                                                    const char *lds, uint32_t *w, int32_t &qd_out)
+                                                    const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq)
 {
   u32x3 e = C.e;
   int32_t p = C.p, d = C.d, m = C.m;
@@ -514,13 +524,23 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
      * placed in the wait states its DPP adds need (see decode_chunk16_quad) */
     uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
     pin(s);
-    uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
-    uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
-    pin(code);
+    uint32_t code = 0, sqw = 0;
+    if (EMIT) {
+      code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
+      pin(code);
+    } else {
+      sqw = (uint32_t)qd * (uint32_t)qd;
+      pin(sqw);
+    }
     s += quad_dpp<0xB1>(s);
     pin(s);
-    acc = (acc << BITS) | code; /* v_lshl_or_b32 */
-    pin(acc);
+    if (EMIT) {
+      uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
+      acc = (acc << BITS) | code; /* v_lshl_or_b32 */
+      pin(acc);
+    } else {
+      sq += (int64_t)(int32_t)sqw;
+    }
     s += quad_dpp<0x4E>(s);
     p = (int32_t)s >> 15;
     d = (j + 1 < kChunk ? x[j + 1 < kChunk ? j + 1 : j] : xn0) - p;
@@ -528,7 +548,6 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     f = (float)d;
     pin(m);
     pin(f);
-    pin(acc);
     if (j + 1 == kChunk) qd_out = qd;
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -1094,44 +1113,11 @@ __device__ __forceinline__ void seed_history(Lane &L, const Src &src, uint64_t f
   L.h1 = n > 2 ? src.at(first + 2) : 0;
   L.h0 = n > 3 ? src.at(first + 3) : 0;
 }
-
-/* RMSE of the dequantised differences over one block while the lane adapts -
- * reference src/aad_encoder.c:431-467.  The squares wrap in int32 like the reference's
- * (SURVEY.md finding 5); every partial sum is an exact integer < 2^53, so accumulating in
- * int64 and converting once equals the reference's running double sum. */
-template <int BITS, typename Src>
-__device__ __forceinline__ double rmse_pass(Lane &L, const Src &src, uint64_t first, uint32_t n,
-                                            const char *lds)
+template <typename Src>
+__device__ __forceinline__ void seed_history(QuadLane &Q, const Src &src, uint64_t first, uint32_t n, uint32_t tap)
 {
-  if (n < (uint32_t)kTaps) return 0.0;
-  seed_history(L, src, first, n);
-  int64_t sum = 0;
-  for (uint32_t i = kTaps; i < n; i++) {
-    int32_t qd;
-    encode_step<BITS>(L, src.at(first + i), lds, qd);
-    sum += (int64_t)(int32_t)((uint32_t)qd * (uint32_t)qd);
-  }
-  return sqrt((double)sum / (double)n);
-}
-
-/* trial search - reference src/aad_encoder.c:470-562 (per channel; channels are independent) */
-template <int BITS, typename Src>
-__device__ __forceinline__ void search_best_lane(Lane &L, const Src &src, uint64_t first, uint32_t n,
-                                                 uint32_t spb, uint32_t trials, const char *lds)
-{
-  const bool have_prev = first >= spb;
-  Lane best = L, run = L, probe = L;
-  double best_rmse = rmse_pass<BITS>(probe, src, first, n, lds);
-  for (uint32_t t = 0; t < trials; t++) {
-    if (have_prev) (void)rmse_pass<BITS>(run, src, first - spb, spb, lds);
-    const Lane cand = run;
-    const double r = rmse_pass<BITS>(run, src, first, n, lds);
-    if (best_rmse > r) {
-      best_rmse = r;
-      best = cand;
-    }
-  }
-  L = best;
+  const uint32_t k = 3u - tap; /* tap t holds the sample that is t steps old: h_t = x[3 - t] */
+  Q.h = k < n ? src.at(first + k) : 0;
 }
 
 __device__ __forceinline__ void store_be16(uint8_t *p, uint32_t v)
@@ -1206,10 +1192,152 @@ __device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w
 }
 
 /*
+ * One pass of the recurrence over the coded samples of a block: samples [first+4, first+n) of
+ * channel c, history already seeded.  EMIT = the real encode pass (codes packed and stored under
+ * `body`); otherwise an RMSE pass of the trial search (reference src/aad_encoder.c:431-467): the
+ * same arithmetic, the int32-wrapped squares of the dequantised differences summed instead of any
+ * output (every partial sum is an exact integer < 2^53, so an int64 sum converted once equals
+ * the reference's running double).  Full 16-sample chunks go through the hand-pipelined bodies
+ * with wide prefetched loads, the rest through encode_step.
+ */
+template <int BITS, int CHF, bool MS, bool QUAD, bool EMIT, typename S>
+__device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t ch,
+                                             uint32_t c, bool writer, uint8_t *body, const char *lds, int32_t &last_qd)
+{
+  constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
+  const uint32_t unit_stride = UB * ch;
+  const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
+  int64_t sq = 0;
+  uint32_t done = 0;
+  {
+    using CS = ChunkSamples<CHF, MS>;
+    const uint32_t full = coded / kChunk;
+    const int16_t *xp = src.x + (first + kTaps) * ch;
+    constexpr uint32_t kOutStride = Pack<BITS>::kChunkBytes;
+    CS next;
+    for (auto &v : next.d) v = 0;
+    if (full) next.load(xp, ch, c);
+    next.touch();
+    if constexpr (QUAD) {
+      /* pipeline carried across chunks: chunk k+1's samples are extracted one chunk early */
+      int32_t x[kChunk], xn[kChunk];
+      EncodeCarry C;
+      if (full) {
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) x[j] = next.get(j, c);
+        if (full > 1) xp += (uint64_t)kChunk * ch;
+        next.load(xp, ch, c);
+        next.touch();
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) xn[j] = next.get(j, c);
+        encode_prime_quad<BITS>(L, C, x[0], lds);
+      }
+      for (uint32_t k = 0; k < full; k++) {
+        if (k + 2 < full) xp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
+        next.load(xp, ch, c);
+        uint32_t w[2] = {0, 0};
+        encode_chunk16_quad<BITS, EMIT>(L, C, x, xn[0], lds, w, last_qd, sq);
+        next.touch();
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) {
+          x[j] = xn[j];
+          xn[j] = next.get(j, c);
+        }
+        if (EMIT && writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD>(body + (uint64_t)k * kOutStride * ch, w, c);
+      }
+    } else {
+      for (uint32_t k = 0; k < full; k++) {
+        int32_t x[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) x[j] = next.get(j, c);
+        /* unconditional prefetch (the last iteration re-reads its own chunk), see the decoder */
+        if (k + 1 < full) xp += (uint64_t)kChunk * ch;
+        next.load(xp, ch, c);
+        uint32_t w[2] = {0, 0};
+        encode_chunk16<BITS, EMIT>(L, x, lds, w, last_qd, sq);
+        next.touch();
+        if (EMIT) {
+          if (CHF != 0) {
+            store_chunk_codes<BITS, (CHF ? CHF : 1), false>(body + (uint64_t)k * kOutStride * ch, w, c);
+          } else { /* any channel count: this lane's unit bytes one by one */
+            uint8_t *up = body + (uint64_t)k * kOutStride * ch + (uint64_t)c * UB;
+#pragma unroll
+            for (int u = 0; u < kChunk / US; u++) {
+              const int per_word = Pack<BITS>::kCodesPerWord / US; /* units per code word */
+              const uint32_t word = w[u / per_word];
+              const uint32_t unit = word >> (8 * UB * (per_word - 1 - (u % per_word)));
+#pragma unroll
+              for (int q = 0; q < UB; q++) up[(uint64_t)u * unit_stride + q] = (uint8_t)(unit >> (8 * (UB - 1 - q)));
+            }
+          }
+        }
+      }
+    }
+    done = full * kChunk;
+  }
+
+  if (EMIT) { /* tail units: samples past n are zero padding - reference :592-593 */
+    uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
+    for (uint32_t i = done; i < coded; i += US, up += unit_stride) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < US; k++) {
+        const int32_t x = i + k < coded ? src.at(first + kTaps + i + k) : 0;
+        acc = (acc << BITS) | encode_step<BITS>(L, x, lds, last_qd);
+      }
+      if (writer) {
+#pragma unroll
+        for (int k = 0; k < UB; k++) up[k] = (uint8_t)(acc >> (8 * (UB - 1 - k)));
+      }
+    }
+  } else { /* an RMSE pass stops at the last real sample (reference :457) */
+    for (uint32_t i = done; i < coded; i++) {
+      int32_t qd;
+      encode_step<BITS>(L, src.at(first + kTaps + i), lds, qd);
+      sq += wrapped_square(qd);
+    }
+  }
+  return sq;
+}
+
+/* RMSE of the dequantised differences over one block while the lane adapts - reference
+ * src/aad_encoder.c:431-467 (divisor = the block length, sum over the coded samples only) */
+template <int BITS, int CHF, bool MS, bool QUAD, typename S>
+__device__ __forceinline__ double rmse_pass(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t ch,
+                                            uint32_t c, uint32_t tap, const char *lds)
+{
+  if (n < (uint32_t)kTaps) return 0.0;
+  if constexpr (QUAD) seed_history(L, src, first, n, tap); else seed_history(L, src, first, n);
+  int32_t qd_unused = 0;
+  const int64_t sum = run_block<BITS, CHF, MS, QUAD, false>(L, src, first, n, ch, c, false, nullptr, lds, qd_unused);
+  return sqrt((double)sum / (double)n);
+}
+
+/* trial search - reference src/aad_encoder.c:470-562 (per channel; channels are independent) */
+template <int BITS, int CHF, bool MS, bool QUAD, typename S>
+__device__ __forceinline__ void search_best_lane(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t spb,
+                                                 uint32_t trials, uint32_t ch, uint32_t c, uint32_t tap, const char *lds)
+{
+  const bool have_prev = first >= spb;
+  S best = L, run = L, probe = L;
+  double best_rmse = rmse_pass<BITS, CHF, MS, QUAD>(probe, src, first, n, ch, c, tap, lds);
+  for (uint32_t t = 0; t < trials; t++) {
+    if (have_prev) (void)rmse_pass<BITS, CHF, MS, QUAD>(run, src, first - spb, spb, ch, c, tap, lds);
+    const S cand = run;
+    const double r = rmse_pass<BITS, CHF, MS, QUAD>(run, src, first, n, ch, c, tap, lds);
+    if (best_rmse > r) {
+      best_rmse = r;
+      best = cand;
+    }
+  }
+  L = best;
+}
+
+/*
  * Stream-parallel encode (reference src/aad_encoder.c:814-891 with EncodeBlock :565-727 and the
  * optional trial search :470-562 inlined).  lane = (stream, channel).
  */
-template <int BITS, int CHF, bool MS, bool QUAD>
+template <int BITS, int CHF, bool MS, bool QUAD, bool TRIALS>
 __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
@@ -1249,100 +1377,21 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
     out[17] = (uint8_t)total;
   }
 
-  constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
-  const uint32_t unit_stride = UB * ch;
   uint64_t block_off = kFileHeaderBytes;
   for (uint64_t first = 0; first < total; first += spb, block_off += a.block_size) {
     const uint32_t n = total - first < spb ? (uint32_t)(total - first) : spb;
-    if (!QUAD && a.trials) search_best_lane<BITS>(F, src, first, n, spb, a.trials, lds); /* host never pairs trials with QUAD */
+    S L;
+    if constexpr (TRIALS) { /* reference src/aad_encoder.c:863-871; a separate instantiation so that the
+                             * trial-free kernel does not carry the search's registers */
+      if constexpr (QUAD) L = to_quad(F, tap); else L = F;
+      search_best_lane<BITS, CHF, MS, QUAD>(L, src, first, n, spb, a.trials, ch, c, tap, lds);
+      if constexpr (QUAD) F = from_quad(L); else F = L;
+    }
     seed_history(F, src, first, n);
     write_block_header(F, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh, writer);
-    S L;
     if constexpr (QUAD) L = to_quad(F, tap); else L = F;
     uint8_t *body = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch;
-    const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
-    uint32_t done = 0;
-
-    {
-      /* full chunks: 16 real samples each, wide loads and stores */
-      using CS = ChunkSamples<CHF, MS>;
-      const uint32_t full = coded / kChunk;
-      const int16_t *xp = src.x + (first + kTaps) * ch;
-      constexpr uint32_t kOutStride = Pack<BITS>::kChunkBytes;
-      CS next;
-      for (auto &v : next.d) v = 0;
-      if (full) next.load(xp, ch, c);
-      next.touch();
-      if constexpr (QUAD) {
-        /* pipeline carried across chunks: chunk k+1's samples are extracted one chunk early */
-        int32_t x[kChunk], xn[kChunk];
-        EncodeCarry C;
-        if (full) {
-#pragma unroll
-          for (int j = 0; j < kChunk; j++) x[j] = next.get(j, c);
-          if (full > 1) xp += (uint64_t)kChunk * ch;
-          next.load(xp, ch, c);
-          next.touch();
-#pragma unroll
-          for (int j = 0; j < kChunk; j++) xn[j] = next.get(j, c);
-          encode_prime_quad<BITS>(L, C, x[0], lds);
-        }
-        for (uint32_t k = 0; k < full; k++) {
-          if (k + 2 < full) xp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
-          next.load(xp, ch, c);
-          uint32_t w[2] = {0, 0};
-          encode_chunk16_quad<BITS>(L, C, x, xn[0], lds, w, last_qd);
-          next.touch();
-#pragma unroll
-          for (int j = 0; j < kChunk; j++) {
-            x[j] = xn[j];
-            xn[j] = next.get(j, c);
-          }
-          if (writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD>(body + (uint64_t)k * kOutStride * ch, w, c);
-        }
-      } else {
-      for (uint32_t k = 0; k < full; k++) {
-        int32_t x[kChunk];
-#pragma unroll
-        for (int j = 0; j < kChunk; j++) x[j] = next.get(j, c);
-        /* unconditional prefetch (the last iteration re-reads its own chunk), see the decoder */
-        if (k + 1 < full) xp += (uint64_t)kChunk * ch;
-        next.load(xp, ch, c);
-        uint32_t w[2] = {0, 0};
-        encode_chunk16<BITS>(L, x, lds, w, last_qd);
-        next.touch();
-        if (CHF != 0) {
-          store_chunk_codes<BITS, (CHF ? CHF : 1), false>(body + (uint64_t)k * kOutStride * ch, w, c);
-        } else { /* any channel count: this lane's unit bytes one by one */
-          uint8_t *up = body + (uint64_t)k * kOutStride * ch + (uint64_t)c * UB;
-#pragma unroll
-          for (int u = 0; u < kChunk / US; u++) {
-            const int per_word = Pack<BITS>::kCodesPerWord / US; /* units per code word */
-            const uint32_t word = w[u / per_word];
-            const uint32_t unit = word >> (8 * UB * (per_word - 1 - (u % per_word)));
-#pragma unroll
-            for (int q = 0; q < UB; q++) up[(uint64_t)u * unit_stride + q] = (uint8_t)(unit >> (8 * (UB - 1 - q)));
-          }
-        }
-      }
-      }
-      done = full * kChunk;
-    }
-
-    /* tail units: samples past n are zero padding - reference :592-593 */
-    uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
-    for (uint32_t i = done; i < coded; i += US, up += unit_stride) {
-      uint32_t acc = 0;
-#pragma unroll
-      for (int k = 0; k < US; k++) {
-        const int32_t x = i + k < coded ? src.at(first + kTaps + i + k) : 0;
-        acc = (acc << BITS) | encode_step<BITS>(L, x, lds, last_qd);
-      }
-      if (writer) {
-#pragma unroll
-        for (int k = 0; k < UB; k++) up[k] = (uint8_t)(acc >> (8 * (UB - 1 - k)));
-      }
-    }
+    (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd);
     if constexpr (QUAD) F = from_quad(L); else F = L;
   }
 

@@ -105,38 +105,43 @@ unsigned pick_workgroup(uint64_t threads) { return threads <= 64ull * 1024ull ? 
  * batch cannot fill the chip anyway, "dense" (one lane per recurrence, fewest total
  * instructions) beyond that.  The crossover is two quad-waves per SIMD.  AAD_HIP_MAPPING=dense|quad
  * overrides the choice (the parity tests run both). */
-bool pick_quad(uint64_t recurrences, uint32_t channels, bool trials)
+bool pick_quad(uint64_t recurrences, uint32_t channels)
 {
-  if (channels > 2 || trials) return false;
+  if (channels > 2) return false;
   const char *e = getenv("AAD_HIP_MAPPING");
   if (e != nullptr && strcmp(e, "dense") == 0) return false;
   if (e != nullptr && strcmp(e, "quad") == 0) return true;
   return recurrences * 4 <= 2ull * 1024ull * 64ull;
 }
 
-template <int BITS, bool QUAD>
+template <int BITS, bool QUAD, bool TRIALS>
 void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
 {
   if (a.channels == 1)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD, TRIALS>), grid, block, 0, stream, a);
   else if (a.channels == 2 && a.mid_side)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD, TRIALS>), grid, block, 0, stream, a);
   else if (a.channels == 2)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD, TRIALS>), grid, block, 0, stream, a);
   else if constexpr (!QUAD)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS>), grid, block, 0, stream, a);
 }
 
 template <int BITS>
 void launch_encode(const aad::EncodeArgs &a, hipStream_t stream)
 {
   const uint64_t lanes = (uint64_t)a.num_streams * a.channels;
-  const bool quad = pick_quad(lanes, a.channels, a.trials != 0);
+  const bool quad = pick_quad(lanes, a.channels);
   const uint64_t threads = quad ? lanes * 4 : lanes;
   const unsigned wg = pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
-  if (quad) launch_encode_mapped<BITS, true>(a, grid, block, stream);
-  else launch_encode_mapped<BITS, false>(a, grid, block, stream);
+  if (a.trials) {
+    if (quad) launch_encode_mapped<BITS, true, true>(a, grid, block, stream);
+    else launch_encode_mapped<BITS, false, true>(a, grid, block, stream);
+  } else {
+    if (quad) launch_encode_mapped<BITS, true, false>(a, grid, block, stream);
+    else launch_encode_mapped<BITS, false, false>(a, grid, block, stream);
+  }
 }
 
 template <int BITS, bool QUAD>
@@ -156,7 +161,7 @@ template <int BITS>
 void launch_decode(const aad::DecodeArgs &a, hipStream_t stream)
 {
   const uint64_t lanes = a.total_blocks * a.channels;
-  const bool quad = pick_quad(lanes, a.channels, false);
+  const bool quad = pick_quad(lanes, a.channels);
   const uint64_t threads = quad ? lanes * 4 : lanes;
   const unsigned wg = pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);

@@ -219,3 +219,65 @@ def test_reference_cli_linked_against_this_library(tmp_path):
         wav = tmp_path / (name + "_decoded.wav")
         subprocess.run([cli, "-d", str(out), str(wav)], check=True, stdout=subprocess.DEVNULL)
         assert wav.read_bytes() == open(os.path.join(FIX, name + "_decoded.wav"), "rb").read()
+
+
+# ---- BASELINE full sizes: size-independent properties + sampled oracle checks ------------------
+
+def _hash_rows(arr):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(arr).tobytes())
+    return h.hexdigest()
+
+
+def test_config5_full_size_10000_files(engine):
+    """BASELINE config 5 shape at full size on one GPU: 10 000 stereo 4-bit files x 10 blocks.
+    Properties: image size = format arithmetic; the two lane mappings (very different code paths)
+    give identical bytes; every 97th stream is bit-exact against the oracle; decode(encode(x))
+    equals the oracle's decode of the same image."""
+    import torch
+    streams, samples = 10000, 9920
+    pcm = synth_pcm(streams, samples, 2, seed=1234)
+    param = make_parameter(2, 4, 1024)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    results = {}
+    for mode in ("dense", "quad"):
+        os.environ["AAD_HIP_MAPPING"] = mode
+        try:
+            d_img, size = engine.encode_uniform(d_pcm, param)
+            d_dec, hd = engine.decode_uniform(d_img, size)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("AAD_HIP_MAPPING", None)
+        results[mode] = (_hash_rows(d_img.cpu().numpy()), _hash_rows(d_dec.cpu().numpy()))
+        assert size == 31 + 10 * 1024
+    assert results["dense"] == results["quad"]
+    img, dec = d_img.cpu().numpy(), d_dec.cpu().numpy()
+    for s in range(0, streams, 97):
+        want = ob.encode(pcm[s], 4, 1024)
+        assert bytes(img[s, :size]) == want, s
+        assert np.array_equal(dec[s], ob.decode(want)[0]), s
+    # lossy codec, but a sane one: reconstruction error far below the signal (reference
+    # test/test_aad_encode_decode.c:303-420 uses RMSE thresholds of the same kind)
+    err = (dec.astype(np.float64) - pcm.astype(np.float64)) / 32768.0
+    assert float(np.sqrt(np.mean(err ** 2))) < 0.05
+
+
+@pytest.mark.parametrize("bits", [3, 2])
+def test_config4_full_size_8_channels(engine, bits):
+    """BASELINE config 4: 10 000 eight-channel one-block segments, 3-bit and 2-bit (the container
+    extension; pinned per channel against the reference's mono encodes in
+    test_eight_channel_lanes_equal_reference_mono)."""
+    import torch
+    spb = {3: 292, 2: 444}[bits]
+    streams = 10000
+    pcm = synth_pcm(streams, spb, 8, seed=4321)
+    param = make_parameter(8, bits, 1024)
+    d_img, size = engine.encode_uniform(torch.from_numpy(pcm).cuda(), param)
+    d_dec, hd = engine.decode_uniform(d_img, size)
+    torch.cuda.synchronize()
+    assert size == 31 + {3: 1008, 2: 1024}[bits] and hd.num_samples_per_block == spb
+    img, dec = d_img.cpu().numpy(), d_dec.cpu().numpy()
+    for s in range(0, streams, 211):
+        want = ob.encode(pcm[s], bits, 1024)
+        assert bytes(img[s, :size]) == want, s
+        assert np.array_equal(dec[s], ob.decode(want)[0]), s
