@@ -71,6 +71,13 @@ HIP_SYMBOLS = [
     "AADHip_EncodePlanDestroy", "AADHip_EncodePlanRun", "AADHip_DecodePlanCreate", "AADHip_DecodePlanDestroy",
     "AADHip_DecodePlanRun", "AADHip_EncodeBatch", "AADHip_DecodeBatch",
 ]
+WAV_SYMBOLS = ["AADWav_ParseHeader", "AADWav_WriteHeader"]
+
+
+class AADWavInfo(C.Structure):  # include/aad_wav.h
+    _fields_ = [("format_tag", C.c_uint16), ("num_channels", C.c_uint16), ("sampling_rate", C.c_uint32),
+                ("bits_per_sample", C.c_uint16), ("num_samples", C.c_uint32), ("data_offset", C.c_uint64),
+                ("data_size", C.c_uint64)]
 
 
 def _declare_legacy(lib):
@@ -137,6 +144,10 @@ def _declare_hip(lib):
     lib.AADHip_EncodeBatch.restype = C.c_int
     lib.AADHip_DecodeBatch.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
     lib.AADHip_DecodeBatch.restype = C.c_int
+    lib.AADWav_ParseHeader.argtypes = [vp, C.c_uint64, C.POINTER(AADWavInfo)]
+    lib.AADWav_ParseHeader.restype = C.c_int
+    lib.AADWav_WriteHeader.argtypes = [vp, C.c_uint32, C.c_uint16, C.c_uint32, C.c_uint32]
+    lib.AADWav_WriteHeader.restype = C.c_int
 
 
 def load_library(path=None, hip=True):

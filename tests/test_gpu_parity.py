@@ -281,3 +281,27 @@ def test_config4_full_size_8_channels(engine, bits):
         want = ob.encode(pcm[s], bits, 1024)
         assert bytes(img[s, :size]) == want, s
         assert np.array_equal(dec[s], ob.decode(want)[0]), s
+
+
+def test_aad_batch_cli_matches_reference_cli_outputs(tmp_path):
+    """N1/N2: the many-file C front end (aad_amd/cli/aad_batch.c) with the reference's default
+    options writes the same bytes as `aad -e` / `aad -d` (the fixtures of test/make_test_data.sh),
+    mono and stereo inputs mixed in one invocation."""
+    import subprocess
+    cli = os.path.join(os.path.dirname(GOLDEN), "..", "aad_amd", "aad_batch")
+    assert os.path.exists(cli), "aad_batch not built"
+    enc_dir, dec_dir = tmp_path / "enc", tmp_path / "dec"
+    enc_dir.mkdir()
+    dec_dir.mkdir()
+    names = ("sin300Hz_mono", "sin300Hz")
+    subprocess.run([cli, "-e", "-o", str(enc_dir)] + [os.path.join(FIX, n + ".wav") for n in names], check=True)
+    for n in names:
+        assert (enc_dir / (n + ".aad")).read_bytes() == open(os.path.join(FIX, n + ".aad"), "rb").read()
+    subprocess.run([cli, "-d", "-o", str(dec_dir)] + [str(enc_dir / (n + ".aad")) for n in names], check=True)
+    for n in names:
+        assert (dec_dir / (n + ".wav")).read_bytes() == open(os.path.join(FIX, n + "_decoded.wav"), "rb").read()
+    # other option values against the oracle
+    subprocess.run([cli, "-e", "-b", "3", "-s", "256", "-t", "0", "-m", "1", "-o", str(enc_dir),
+                    os.path.join(FIX, "unit_impulse.wav")], check=True)
+    pcm, rate = read_wav16(os.path.join(FIX, "unit_impulse.wav"))
+    assert (enc_dir / "unit_impulse.aad").read_bytes() == ob.encode(pcm, 3, 256, rate, True, 0)

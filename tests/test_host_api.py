@@ -10,7 +10,8 @@ import pytest
 
 import aad_amd
 from aad_amd import AADApiResult as R
-from aad_amd.capi import HIP_SYMBOLS, LEGACY_SYMBOLS, AADEncodeParameter, AADHeaderInfo, make_parameter
+from aad_amd.capi import (HIP_SYMBOLS, LEGACY_SYMBOLS, WAV_SYMBOLS, AADEncodeParameter, AADHeaderInfo, AADWavInfo,
+                          make_parameter)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -22,10 +23,10 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     declared = set()
-    for h in ("aad_encoder.h", "aad_decoder.h", "aad_hip.h"):
+    for h in ("aad_api.h", "aad_hip.h", "aad_wav.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
-        declared |= set(re.findall(r"\b(AAD(?:Encoder|Decoder|Hip)_[A-Za-z]+)\s*\(", text))
-    assert declared == set(LEGACY_SYMBOLS) | set(HIP_SYMBOLS)
+        declared |= set(re.findall(r"\b(AAD(?:Encoder|Decoder|Hip|Wav)_[A-Za-z]+)\s*\(", text))
+    assert declared == set(LEGACY_SYMBOLS) | set(HIP_SYMBOLS) | set(WAV_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
 
@@ -261,3 +262,33 @@ def test_encoded_size_matches_formula(lib):
     assert lib.AADHip_CalculateEncodedSize(C.byref(m), 24000) == 12223          # sin300Hz_mono.aad
     p8 = make_parameter(8, 3, 1024)
     assert lib.AADHip_CalculateEncodedSize(C.byref(p8), 292) == 31 + 1008
+
+
+def test_wav_helpers_match_reference_fixtures(lib):
+    """N1: the 16-bit PCM WAV payload is the device layout; the 44-byte header written for a decode
+    equals the one in the reference's decoded fixtures (src/wav.c:545-627)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import GOLDEN, read_wav16
+    fix = os.path.join(GOLDEN, "ref_fixtures")
+    for name in ("sin300Hz.wav", "sin300Hz_mono.wav", "unit_impulse.wav", "unit_impulse_mono.wav", "sin300Hz_decoded.wav"):
+        raw = np.frombuffer(open(os.path.join(fix, name), "rb").read(), dtype=np.uint8)
+        info = AADWavInfo()
+        assert lib.AADWav_ParseHeader(raw.ctypes.data, len(raw), C.byref(info)) == R.OK
+        pcm, rate = read_wav16(os.path.join(fix, name))
+        assert (info.format_tag, info.num_channels, info.sampling_rate, info.bits_per_sample) == (1, pcm.shape[1], rate, 16)
+        assert info.num_samples == pcm.shape[0] and info.data_size == pcm.size * 2
+        payload = raw[info.data_offset: info.data_offset + info.data_size].view("<i2").reshape(-1, pcm.shape[1])
+        assert np.array_equal(payload, pcm)
+    for name in ("sin300Hz_decoded.wav", "sin300Hz_mono_decoded.wav"):
+        raw = open(os.path.join(fix, name), "rb").read()
+        pcm, rate = read_wav16(os.path.join(fix, name))
+        head = (C.c_uint8 * 44)()
+        assert lib.AADWav_WriteHeader(head, 44, pcm.shape[1], rate, pcm.shape[0]) == R.OK
+        assert bytes(head) == raw[:44]
+    info = AADWavInfo()
+    bad = np.frombuffer(b"RIFX" + bytes(60), dtype=np.uint8)
+    assert lib.AADWav_ParseHeader(bad.ctypes.data, len(bad), C.byref(info)) == R.INVALID_FORMAT
+    assert lib.AADWav_ParseHeader(bad.ctypes.data, 8, C.byref(info)) == R.INSUFFICIENT_DATA
+    assert lib.AADWav_ParseHeader(None, 64, C.byref(info)) == R.INVALID_ARGUMENT
+    assert lib.AADWav_WriteHeader((C.c_uint8 * 44)(), 43, 2, 48000, 10) == R.INSUFFICIENT_BUFFER
