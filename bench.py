@@ -91,8 +91,8 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=pcm.device)
+    if world > 1: # MAX over ranks
+        t = torch.tensor([dt], dtype=torch.float64, device=pcm.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     timed = [e for e in evs if e is not None]
@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true")
     ap.add_argument("--saturated-streams", type=int, default=262144)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--event-every", type=int, default=8, help="bracket the kernels with HIP events on every n-th timed step")
     args = ap.parse_args()
 
@@ -197,9 +198,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the AAD engine has no CPU path")
+    local = local % torch.cuda.device_count()  # (a 1-GPU box can rehearse N>1 with --backend gloo)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":  # RCCL on ROCm
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     from aad_amd.capi import make_parameter
     from aad_amd.engine import Engine
