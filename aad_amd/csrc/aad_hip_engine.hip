@@ -20,11 +20,20 @@
 static_assert(sizeof(AADHipStreamDesc) == sizeof(aad::StreamDesc), "stream table layout");
 static_assert(sizeof(AADHipLaneState) == sizeof(aad::LaneStateRecord), "lane state layout");
 
+/* grow-only pinned-host + device buffer pair used by the host-memory convenience calls: all
+ * streams of a batch are packed into ONE pinned block and cross PCIe in ONE copy each way
+ * (a copy per stream from pageable memory cost ~10 us apiece: 20 ms for the 1000-stream batch) */
+struct Staging {
+  void *host = nullptr, *dev = nullptr;
+  size_t cap = 0;
+};
+
 struct AADHipContext {
   int device;
   hipStream_t stream;
   bool owns_stream;
   char last_error[256];
+  Staging pcm, data;
 };
 
 struct AADHipEncodePlan {
@@ -82,6 +91,29 @@ aad::UniformLayout detect_uniform(uint32_t n, const AADHipStreamDesc *t)
   u.num_samples = t[0].num_samples;
   u.enabled = 1;
   return u;
+}
+
+bool hip_ok(AADHipContext *ctx, hipError_t e, const char *what);
+
+bool staging_reserve(AADHipContext *ctx, Staging &st, size_t bytes)
+{
+  if (bytes <= st.cap) return true;
+  if (st.host) (void)hipHostFree(st.host);
+  if (st.dev) (void)hipFree(st.dev);
+  st.host = st.dev = nullptr;
+  st.cap = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  if (!hip_ok(ctx, hipHostMalloc(&st.host, want, hipHostMallocDefault), "hipHostMalloc")) return false;
+  if (!hip_ok(ctx, hipMalloc(&st.dev, want), "hipMalloc staging")) return false;
+  st.cap = want;
+  return true;
+}
+
+void staging_release(Staging &st)
+{
+  if (st.host) (void)hipHostFree(st.host);
+  if (st.dev) (void)hipFree(st.dev);
+  st = Staging();
 }
 
 template <typename T>
@@ -217,6 +249,8 @@ void AADHip_ContextDestroy(struct AADHipContext *ctx)
     DeviceGuard guard(ctx);
     if (guard.ok) {
       (void)hipStreamSynchronize(ctx->stream);
+      staging_release(ctx->pcm);
+      staging_release(ctx->data);
       if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     }
   }
@@ -461,29 +495,25 @@ AADApiResult AADHip_EncodeBatch(struct AADHipContext *ctx, const struct AADEncod
   AADApiResult rc = AADHip_EncodePlanCreate(ctx, parameter, num_streams, table.data(), &plan);
   if (rc != AAD_APIRESULT_OK) return rc;
   DeviceGuard guard(ctx);
-  DeviceBuffer d_pcm, d_data, d_state;
+  DeviceBuffer d_state;
   const size_t state_bytes = sizeof(AADHipLaneState) * (size_t)num_streams * ch;
+  const size_t pcm_bytes = pcm_elems * sizeof(int16_t);
   rc = AAD_APIRESULT_NG;
   do {
     if (!guard.ok) break;
-    if (!hip_ok(ctx, hipMalloc(&d_pcm.p, pcm_elems * sizeof(int16_t) + 64), "hipMalloc pcm")) break;
-    if (!hip_ok(ctx, hipMalloc(&d_data.p, data_bytes + 64), "hipMalloc data")) break;
+    if (!staging_reserve(ctx, ctx->pcm, pcm_bytes + 64) || !staging_reserve(ctx, ctx->data, data_bytes + 64)) break;
     if (state) {
       if (!hip_ok(ctx, hipMalloc(&d_state.p, state_bytes), "hipMalloc state")) break;
       if (!hip_ok(ctx, hipMemcpyAsync(d_state.p, state, state_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D state")) break;
     }
-    bool ok = true;
-    for (uint32_t i = 0; i < num_streams && ok; i++)
-      ok = hip_ok(ctx, hipMemcpyAsync((int16_t *)d_pcm.p + table[i].pcm_offset, pcm[i],
-                                      (size_t)num_samples[i] * ch * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream), "H2D pcm");
-    if (!ok) break;
-    if (AADHip_EncodePlanRun(plan, (const int16_t *)d_pcm.p, (uint8_t *)d_data.p, (AADHipLaneState *)d_state.p) != AAD_APIRESULT_OK) break;
-    for (uint32_t i = 0; i < num_streams && ok; i++)
-      ok = hip_ok(ctx, hipMemcpyAsync(data[i], (uint8_t *)d_data.p + table[i].data_offset, sizes[i],
-                                      hipMemcpyDeviceToHost, ctx->stream), "D2H data");
-    if (!ok) break;
+    for (uint32_t i = 0; i < num_streams; i++)
+      memcpy((int16_t *)ctx->pcm.host + table[i].pcm_offset, pcm[i], (size_t)num_samples[i] * ch * sizeof(int16_t));
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->pcm.dev, ctx->pcm.host, pcm_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D pcm")) break;
+    if (AADHip_EncodePlanRun(plan, (const int16_t *)ctx->pcm.dev, (uint8_t *)ctx->data.dev, (AADHipLaneState *)d_state.p) != AAD_APIRESULT_OK) break;
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->data.host, ctx->data.dev, data_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H data")) break;
     if (state && !hip_ok(ctx, hipMemcpyAsync(state, d_state.p, state_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H state")) break;
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
+    for (uint32_t i = 0; i < num_streams; i++) memcpy(data[i], (uint8_t *)ctx->data.host + table[i].data_offset, sizes[i]);
     if (output_size) memcpy(output_size, sizes.data(), sizeof(uint64_t) * num_streams);
     rc = AAD_APIRESULT_OK;
   } while (0);
@@ -518,24 +548,19 @@ AADApiResult AADHipInternal_DecodeHost(struct AADHipContext *ctx, const struct A
   AADApiResult rc = AADHip_DecodePlanCreate(ctx, format, has_file_header, num_streams, table.data(), &plan);
   if (rc != AAD_APIRESULT_OK) return rc;
   DeviceGuard guard(ctx);
-  DeviceBuffer d_pcm, d_data;
+  const size_t pcm_bytes = pcm_elems * sizeof(int16_t);
   rc = AAD_APIRESULT_NG;
   do {
     if (!guard.ok) break;
-    if (!hip_ok(ctx, hipMalloc(&d_pcm.p, pcm_elems * sizeof(int16_t) + 64), "hipMalloc pcm")) break;
-    if (!hip_ok(ctx, hipMalloc(&d_data.p, data_bytes + 64), "hipMalloc data")) break;
-    bool ok = true;
-    for (uint32_t i = 0; i < num_streams && ok; i++)
-      ok = hip_ok(ctx, hipMemcpyAsync((uint8_t *)d_data.p + table[i].data_offset, data[i], data_size[i],
-                                      hipMemcpyHostToDevice, ctx->stream), "H2D data");
-    if (!ok) break;
-    if (AADHip_DecodePlanRun(plan, (const uint8_t *)d_data.p, (int16_t *)d_pcm.p) != AAD_APIRESULT_OK) break;
-    for (uint32_t i = 0; i < num_streams && ok; i++)
-      if (decoded[i])
-        ok = hip_ok(ctx, hipMemcpyAsync(pcm[i], (int16_t *)d_pcm.p + table[i].pcm_offset,
-                                        (size_t)decoded[i] * ch * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream), "D2H pcm");
-    if (!ok) break;
+    if (!staging_reserve(ctx, ctx->pcm, pcm_bytes + 64) || !staging_reserve(ctx, ctx->data, data_bytes + 64)) break;
+    for (uint32_t i = 0; i < num_streams; i++) memcpy((uint8_t *)ctx->data.host + table[i].data_offset, data[i], data_size[i]);
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->data.dev, ctx->data.host, data_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D data")) break;
+    if (AADHip_DecodePlanRun(plan, (const uint8_t *)ctx->data.dev, (int16_t *)ctx->pcm.dev) != AAD_APIRESULT_OK) break;
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->pcm.host, ctx->pcm.dev, pcm_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H pcm")) break;
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
+    for (uint32_t i = 0; i < num_streams; i++)
+      if (decoded[i])
+        memcpy(pcm[i], (int16_t *)ctx->pcm.host + table[i].pcm_offset, (size_t)decoded[i] * ch * sizeof(int16_t));
     if (decoded_frames) memcpy(decoded_frames, decoded.data(), sizeof(uint32_t) * num_streams);
     rc = AAD_APIRESULT_OK;
   } while (0);

@@ -305,3 +305,48 @@ def test_aad_batch_cli_matches_reference_cli_outputs(tmp_path):
                     os.path.join(FIX, "unit_impulse.wav")], check=True)
     pcm, rate = read_wav16(os.path.join(FIX, "unit_impulse.wav"))
     assert (enc_dir / "unit_impulse.aad").read_bytes() == ob.encode(pcm, 3, 256, rate, True, 0)
+
+
+def test_random_access_block_ranges(engine):
+    """every block header carries the full predictor state, so any block
+    range decodes on its own - here as a batch of bare blocks (has_file_header = 0) picked out of
+    the middle of several streams, equal to the same slices of the full decodes."""
+    import torch
+    from aad_amd.capi import STREAM_DESC_DTYPE
+    from aad_amd.engine import parse_header
+    pcms = [synth_pcm(1, 9000 + 500 * i, 2, seed=300 + i)[0] for i in range(4)]
+    images = [ob.encode(p, 4, 1024, 48000, False, 1) for p in pcms]
+    full = [ob.decode(img)[0] for img in images]
+    hd = parse_header(images[0][:31])
+    spb, bs = hd.num_samples_per_block, hd.block_size
+    picks = [(0, 3, 2), (1, 0, 1), (2, 5, 4), (3, 8, 1), (0, 9, 1)]   # (stream, first block, block count)
+    blob, descs, pcm_off = bytearray(), [], 0
+    for s, b0, nb in picks:
+        chunk = images[s][31 + b0 * bs: 31 + (b0 + nb) * bs]
+        frames = min(nb * spb, len(full[s]) - b0 * spb)
+        descs.append((pcm_off, len(blob), len(chunk), frames, 0))
+        blob += chunk + bytes(-len(chunk) % 16)
+        pcm_off += frames * 2
+    d = np.array(descs, dtype=STREAM_DESC_DTYPE)
+    plan = engine.decode_plan(hd, d, has_file_header=False)
+    d_data = torch.from_numpy(np.frombuffer(bytes(blob), dtype=np.uint8).copy()).cuda()
+    d_pcm = torch.zeros(pcm_off, dtype=torch.int16, device="cuda")
+    plan.run(d_data, d_pcm)
+    torch.cuda.synchronize()
+    got = d_pcm.cpu().numpy()
+    for (s, b0, nb), row in zip(picks, descs):
+        frames = row[3]
+        assert np.array_equal(got[row[0]: row[0] + frames * 2].reshape(-1, 2), full[s][b0 * spb: b0 * spb + frames]), (s, b0)
+
+
+def test_extreme_block_sizes(engine, mapping):
+    """geometry extremes: the largest block the 16-bit header field allows and the smallest that
+    still carries data (reference src/aad_encoder.c:85-131)"""
+    for ch, bits, mbs, n in ((2, 4, 65535, 70000), (1, 3, 65535, 180000), (2, 4, 38, 500), (1, 2, 19, 300), (2, 3, 42, 777)):
+        pcm = synth_pcm(2, n, ch, seed=mbs)
+        images = engine.encode_host([pcm[0], pcm[1]], make_parameter(ch, bits, mbs, 48000, False, 0))
+        for s in range(2):
+            assert images[s] == ob.encode(pcm[s], bits, mbs), (ch, bits, mbs)
+        dec = engine.decode_host(images)
+        for s in range(2):
+            assert np.array_equal(dec[s], ob.decode(images[s])[0]), (ch, bits, mbs)

@@ -37,6 +37,25 @@ def run(eng, name, streams, samples, ch, bits, trials=0, reps=10):
                 encode_msps=round(n / (te / reps) / 1e3, 1), decode_msps=round(n / (td / reps) / 1e3, 1))
 
 
+def host_api(eng, streams, samples, ch, bits, reps=5):
+    """PCIe-inclusive rate of the host-memory convenience calls (stage + kernel + copy back)."""
+    import time
+    import numpy as np
+    pcm = synth_pcm(min(streams, 500), samples, ch, seed=7)
+    pcm = np.concatenate([pcm] * (-(-streams // pcm.shape[0])))[:streams]
+    param = make_parameter(ch, bits, 1024, 48000, False, 0)
+    rows = [pcm[i] for i in range(streams)]
+    imgs = eng.encode_host(rows, param)
+    te = td = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter(); imgs = eng.encode_host(rows, param); t1 = time.perf_counter()
+        eng.decode_host(imgs); t2 = time.perf_counter()
+        te, td = min(te, t1 - t0), min(td, t2 - t1)
+    n = streams * samples * ch
+    return dict(config="host API (pageable memory, incl. H2D/D2H) %d stereo x1 block" % streams, encode_ms=round(te * 1e3, 3),
+                decode_ms=round(td * 1e3, 3), encode_msps=round(n / te / 1e6, 1), decode_msps=round(n / td / 1e6, 1))
+
+
 def main():
     eng = Engine(0)
     torch.cuda.set_stream(eng.stream)
@@ -48,7 +67,8 @@ def main():
             run(eng, "cfg4ref 40000 stereo 3-bit", 40000, 1316, 2, 3),
             run(eng, "cfg5 shard 1250 files x10 blocks", 1250, 9920, 2, 4, reps=5),
             run(eng, "cfg5 all 10000 files x10 blocks", 10000, 9920, 2, 4, reps=3),
-            run(eng, "cfg2 t=2", 1000, 992, 2, 4, trials=2)]
+            run(eng, "cfg2 t=2", 1000, 992, 2, 4, trials=2),
+            host_api(eng, 1000, 992, 2, 4)]
     for r in rows:
         print(json.dumps(r))
 
