@@ -169,37 +169,32 @@ def cpu_baseline(pcm_np, param_kw, budget_s=8.0):
         best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
         reps += 1
     n = streams * samples * ch
-    # all-cores figure (SURVEY.md section 8d "for honesty"): the same batch split over threads,
-    # one codec handle per call (ctypes drops the GIL inside the C calls)
-    all_cores = None
-    if kind == "reference":
-        from concurrent.futures import ThreadPoolExecutor
-        threads = max(1, min(os.cpu_count() or 1, 16))
+    # all-cores figure (SURVEY.md section 8d "for honesty"): the oracle's batch entry points, one
+    # C call per thread over a contiguous slice of the streams (ctypes drops the GIL for the whole
+    # call; per-stream calls into the reference library would be Python-bound), kind "port"
+    from concurrent.futures import ThreadPoolExecutor
+    o = ob.lib()
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    flat = np.ascontiguousarray(pcm_np)
+    stride = ob.encoded_size(samples, ch, bits, mbs)
+    p_out = np.zeros((streams, stride), dtype=np.uint8)
+    p_dec = np.zeros((streams, samples, ch), dtype=np.int16)
+    bounds = [(t * streams // threads, (t + 1) * streams // threads) for t in range(threads)]
 
-        def enc_slice(t):
-            for s in range(t, streams, threads):
-                e = lib.AADEncoder_Create(mbs, None, 0)
-                lib.AADEncoder_SetEncodeParameter(e, C.byref(param))
-                sz = C.c_uint32()
-                lib.AADEncoder_EncodeWhole(e, rows_in[s], samples, outs[s].ctypes.data_as(u8p), cap, C.byref(sz))
-                lib.AADEncoder_Destroy(e)
+    def port_slice(lohi):
+        lo, hi = lohi
+        if hi > lo:
+            o.aado_encode_batch(flat[lo:hi].ctypes.data, hi - lo, samples, ch, 48000, bits, mbs, 0, trials,
+                                p_out[lo:hi].ctypes.data, stride)
+            o.aado_decode_batch(p_out[lo:hi].ctypes.data, hi - lo, stride, stride, p_dec[lo:hi].ctypes.data, samples)
 
-        def dec_slice(t):
-            buf = np.zeros((ch, samples), dtype=np.int32)
-            rows = _planar_pointers(buf)
-            for s in range(t, streams, threads):
-                d = lib.AADDecoder_Create(None, 0)
-                lib.AADDecoder_DecodeWhole(d, outs[s].ctypes.data_as(u8p), int(sizes[s]), rows, ch, samples)
-                lib.AADDecoder_Destroy(d)
-
-        with ThreadPoolExecutor(threads) as pool:
-            best = 1e9
-            for _ in range(5):
-                t0 = time.perf_counter()
-                list(pool.map(enc_slice, range(threads)))
-                list(pool.map(dec_slice, range(threads)))
-                best = min(best, time.perf_counter() - t0)
-        all_cores = dict(value=round(2 * n / best / 1e6, 3), unit="Msamples/s", cores=threads)
+    with ThreadPoolExecutor(threads) as pool:
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            list(pool.map(port_slice, bounds))
+            best = min(best, time.perf_counter() - t0)
+    all_cores = dict(value=round(2 * n / best / 1e6, 3), unit="Msamples/s", cores=threads, kind="port")
     return dict(value=round(2 * n / (best_e + best_d) / 1e6, 3), unit="Msamples/s", cores=1, kind=kind, all_cores=all_cores,
                 sample="%d stereo streams x %d samples/ch (the full step batch), encode+decode, best of %d passes, 1 thread"
                        % (streams, samples, reps),
