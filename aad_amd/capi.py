@@ -53,6 +53,8 @@ class AADHipLaneState(C.Structure):  # include/aad_hip.h
 
 STREAM_DESC_DTYPE = np.dtype([("pcm_offset", "<u8"), ("data_offset", "<u8"), ("data_size", "<u8"),
                               ("num_samples", "<u4"), ("reserved", "<u4")])
+ERROR_STATS_DTYPE = np.dtype([("rms_error", "<f8"), ("mean_abs_error", "<f8"), ("max_abs_error", "<f8")])  # AADHipErrorStats
+RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL = 0, 1  # enum AADHipReconstructOutput
 LANE_STATE_DTYPE = np.dtype([("weight", "<i4", (4,)), ("history", "<i4", (4,)),
                              ("stepsize_index", "<i4"), ("quantize_error", "<i4")])
 
@@ -70,6 +72,8 @@ HIP_SYMBOLS = [
     "AADHip_ContextLastError", "AADHip_CalculateEncodedSize", "AADHip_EncodePlanCreate",
     "AADHip_EncodePlanDestroy", "AADHip_EncodePlanRun", "AADHip_DecodePlanCreate", "AADHip_DecodePlanDestroy",
     "AADHip_DecodePlanRun", "AADHip_EncodeBatch", "AADHip_DecodeBatch",
+    "AADHip_ReconstructPlanCreate", "AADHip_ReconstructPlanDestroy", "AADHip_ReconstructPlanRun",
+    "AADHip_ReconstructBatch",
 ]
 WAV_SYMBOLS = ["AADWav_ParseHeader", "AADWav_WriteHeader"]
 
@@ -144,6 +148,14 @@ def _declare_hip(lib):
     lib.AADHip_EncodeBatch.restype = C.c_int
     lib.AADHip_DecodeBatch.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
     lib.AADHip_DecodeBatch.restype = C.c_int
+    lib.AADHip_ReconstructPlanCreate.argtypes = [vp, C.POINTER(AADEncodeParameter), C.c_uint32, vp, C.POINTER(vp)]
+    lib.AADHip_ReconstructPlanCreate.restype = C.c_int
+    lib.AADHip_ReconstructPlanDestroy.argtypes = [vp]
+    lib.AADHip_ReconstructPlanDestroy.restype = None
+    lib.AADHip_ReconstructPlanRun.argtypes = [vp, vp, vp, vp, C.c_int32, vp]
+    lib.AADHip_ReconstructPlanRun.restype = C.c_int
+    lib.AADHip_ReconstructBatch.argtypes = [vp, C.POINTER(AADEncodeParameter), C.c_uint32, vp, vp, C.c_int32, vp, vp]
+    lib.AADHip_ReconstructBatch.restype = C.c_int
     lib.AADWav_ParseHeader.argtypes = [vp, C.c_uint64, C.POINTER(AADWavInfo)]
     lib.AADWav_ParseHeader.restype = C.c_int
     lib.AADWav_WriteHeader.argtypes = [vp, C.c_uint32, C.c_uint16, C.c_uint32, C.c_uint32]

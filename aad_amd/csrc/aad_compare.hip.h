@@ -1,0 +1,148 @@
+/*
+ * aad_compare.hip.h - device side of the reconstruction modes:
+ * residual output and the RMSE / MSD / MaxAE figures of the reference CLI's -r / -g / -c
+ * (src/main.c:275-503), computed where encode -> decode left the two PCM buffers: in HBM.
+ *
+ * The arithmetic per value is the CLI's, literally (src/main.c:470-491): with x the original and
+ * y the reconstructed int16,
+ *     g  = (x << 16) - (y << 16)            32-bit wrap, the WAV reader's domain
+ *     e  = (double)g / INT32_MAX - (double)y / INT32_MAX
+ *     RMSE = sqrt(sum e^2 / N), MSD = sum |e| / N, MaxAE = max |e|
+ * (that the second operand is y and not y << 16 is how the reference is written; a drop-in
+ * prints what it prints).  fp64 division on gfx950 is IEEE-exact, so every e is bit-identical to
+ * the host's; only the ORDER of the fp64 sums differs (fixed tree here, channel-major walk
+ * there), a relative difference of ~1e-14 that never reaches the six decimals the CLI prints.
+ *
+ * HBM-bound by construction: 4 B read (+2 B written for the residual) per value, nothing else.
+ */
+#ifndef AAD_COMPARE_HIP_H_INCLUDED
+#define AAD_COMPARE_HIP_H_INCLUDED
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aad_device.hip.h"
+
+namespace aad {
+
+constexpr uint32_t kCompareThreads = 256;
+constexpr uint32_t kCompareValuesPerThread = 32;
+constexpr uint32_t kCompareSegment = kCompareThreads * kCompareValuesPerThread; /* int16 values per workgroup */
+
+struct ErrorPartial {
+  double sum_sq, sum_abs, max_abs;
+};
+
+struct ErrorStatsRecord { /* == AADHipErrorStats */
+  double rms_error, mean_abs_error, max_abs_error;
+};
+
+struct CompareArgs {
+  const StreamDesc *streams;
+  const uint64_t *segment_prefix; /* [num_streams + 1] exclusive prefix sum of segments per stream */
+  const int16_t *original;
+  int16_t *decoded;      /* read; overwritten with the residual when write_residual != 0 */
+  ErrorPartial *partials; /* [total_segments]; null when no statistics are wanted */
+  ErrorStatsRecord *stats; /* [num_streams] */
+  uint64_t total_segments;
+  uint32_t num_streams;
+  uint32_t channels;
+  uint32_t write_residual;
+  uint32_t reserved;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+/* one workgroup per kCompareSegment values of one stream */
+__global__ __launch_bounds__(kCompareThreads) void compare_segments_kernel(CompareArgs a)
+{
+  __shared__ ErrorPartial wave_part[kCompareThreads / 64];
+  const uint64_t g = blockIdx.x;
+  if (g >= a.total_segments) return;
+  const uint32_t s = find_stream(a.segment_prefix, a.num_streams, g);
+  const StreamDesc sd = a.streams[s];
+  const uint64_t count = (uint64_t)sd.num_samples * a.channels;
+  const uint64_t first = (g - a.segment_prefix[s]) * kCompareSegment;
+  const int16_t *x = a.original + sd.pcm_offset;
+  int16_t *y = a.decoded + sd.pcm_offset;
+
+  double sq = 0.0, ab = 0.0, mx = 0.0;
+#pragma unroll 4
+  for (uint32_t k = 0; k < kCompareValuesPerThread; k++) {
+    const uint64_t i = first + (uint64_t)k * kCompareThreads + threadIdx.x;
+    if (i >= count) break;
+    const int32_t xv = x[i], yv = y[i];
+    const int32_t gap = (int32_t)(((uint32_t)xv << 16) - ((uint32_t)yv << 16)); /* src/main.c:470-474 */
+    if (a.partials != nullptr) {
+      const double e = (double)gap / 2147483647.0 - (double)yv / 2147483647.0; /* src/main.c:483-486 */
+      const double m = fabs(e);
+      sq += e * e;
+      ab += m;
+      mx = fmax(mx, m);
+    }
+    if (a.write_residual) y[i] = (int16_t)(gap >> 16); /* the 16-bit writer keeps the top half, src/wav.c:429 */
+  }
+  if (a.partials == nullptr) return;
+  sq = wave_sum(sq);
+  ab = wave_sum(ab);
+  mx = wave_max(mx);
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    wave_part[wave].sum_sq = sq;
+    wave_part[wave].sum_abs = ab;
+    wave_part[wave].max_abs = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ErrorPartial p = wave_part[0];
+    for (uint32_t w = 1; w < kCompareThreads / 64; w++) {
+      p.sum_sq += wave_part[w].sum_sq;
+      p.sum_abs += wave_part[w].sum_abs;
+      p.max_abs = fmax(p.max_abs, wave_part[w].max_abs);
+    }
+    a.partials[g] = p;
+  }
+}
+
+/* one wave per stream: fold its segment partials in a fixed order, then the CLI's final three lines */
+__global__ __launch_bounds__(64) void compare_finish_kernel(CompareArgs a)
+{
+  const uint32_t s = blockIdx.x;
+  if (s >= a.num_streams) return;
+  const uint64_t lo = a.segment_prefix[s], hi = a.segment_prefix[s + 1];
+  double sq = 0.0, ab = 0.0, mx = 0.0;
+  for (uint64_t g = lo + threadIdx.x; g < hi; g += 64) {
+    const ErrorPartial p = a.partials[g];
+    sq += p.sum_sq;
+    ab += p.sum_abs;
+    mx = fmax(mx, p.max_abs);
+  }
+  sq = wave_sum(sq);
+  ab = wave_sum(ab);
+  mx = wave_max(mx);
+  if (threadIdx.x == 0) {
+    /* the CLI divides by the uint32 product (src/main.c:494-496) */
+    const double n = (double)(uint32_t)(a.channels * a.streams[s].num_samples);
+    ErrorStatsRecord r;
+    r.rms_error = sqrt(sq / n);
+    r.mean_abs_error = ab / n;
+    r.max_abs_error = mx;
+    a.stats[s] = r;
+  }
+}
+
+} /* namespace aad */
+
+#endif /* AAD_COMPARE_HIP_H_INCLUDED */

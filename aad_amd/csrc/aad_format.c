@@ -111,8 +111,8 @@ AADApiResult AADFormat_ParameterToHeader(const struct AADEncodeParameter *p, uin
   if (p->bits_per_sample == 0 || p->bits_per_sample > AAD_MAX_BITS_PER_SAMPLE) return AAD_APIRESULT_INVALID_FORMAT;
   if (p->max_block_size < AAD_BLOCK_HEADER_BYTES_PER_CH * (uint32_t)p->num_channels) return AAD_APIRESULT_INVALID_FORMAT;
   if ((uint32_t)p->ch_process_method >= (uint32_t)AAD_CH_PROCESS_METHOD_INVALID) return AAD_APIRESULT_INVALID_FORMAT;
-  h.format_version = 0;
-  h.codec_version = 0;
+  h.format_version = AAD_FORMAT_VERSION; /* what the encoder writes, src/aad_encoder.c:195-200 */
+  h.codec_version = AAD_CODEC_VERSION;
   h.num_channels = p->num_channels;
   h.num_samples = num_samples;
   h.sampling_rate = p->sampling_rate;

@@ -13,12 +13,14 @@
 #include <vector>
 
 #include "../../include/aad_hip.h"
+#include "aad_compare.hip.h"
 #include "aad_device.hip.h"
 #include "aad_format.h"
 #include "aad_hip_internal.h"
 
 static_assert(sizeof(AADHipStreamDesc) == sizeof(aad::StreamDesc), "stream table layout");
 static_assert(sizeof(AADHipLaneState) == sizeof(aad::LaneStateRecord), "lane state layout");
+static_assert(sizeof(AADHipErrorStats) == sizeof(aad::ErrorStatsRecord), "error stats layout");
 
 /* grow-only pinned-host + device buffer pair used by the host-memory convenience calls: all
  * streams of a batch are packed into ONE pinned block and cross PCIe in ONE copy each way
@@ -33,7 +35,7 @@ struct AADHipContext {
   hipStream_t stream;
   bool owns_stream;
   char last_error[256];
-  Staging pcm, data;
+  Staging pcm, data, pcm_out;
 };
 
 struct AADHipEncodePlan {
@@ -47,6 +49,15 @@ struct AADHipDecodePlan {
   aad::DecodeArgs args;
   aad::StreamDesc *d_streams;
   uint64_t *d_prefix;
+};
+
+struct AADHipReconstructPlan {
+  AADHipContext *ctx;
+  AADHipEncodePlan *encode;
+  AADHipDecodePlan *decode;
+  aad::CompareArgs args; /* streams -> the decode plan's table */
+  uint64_t *d_segment_prefix;
+  aad::ErrorPartial *d_partials;
 };
 
 namespace {
@@ -251,6 +262,7 @@ void AADHip_ContextDestroy(struct AADHipContext *ctx)
       (void)hipStreamSynchronize(ctx->stream);
       staging_release(ctx->pcm);
       staging_release(ctx->data);
+      staging_release(ctx->pcm_out);
       if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     }
   }
@@ -595,6 +607,155 @@ AADApiResult AADHip_DecodeBatch(struct AADHipContext *ctx, uint32_t num_streams,
     frames[i] = h.num_samples;
   }
   return AADHipInternal_DecodeHost(ctx, &format, 1, num_streams, data, data_size, frames.data(), pcm, decoded_frames);
+}
+
+/* ------------------------------------------------------------------- reconstruction modes -- */
+
+AADApiResult AADHip_ReconstructPlanCreate(struct AADHipContext *ctx, const struct AADEncodeParameter *parameter,
+                                          uint32_t num_streams, const struct AADHipStreamDesc *streams,
+                                          struct AADHipReconstructPlan **plan)
+{
+  if (ctx == nullptr || parameter == nullptr || plan == nullptr || (num_streams != 0 && streams == nullptr))
+    return AAD_APIRESULT_INVALID_ARGUMENT;
+  *plan = nullptr;
+  AADHipReconstructPlan *p = new (std::nothrow) AADHipReconstructPlan();
+  if (p == nullptr) return AAD_APIRESULT_NG;
+  memset(static_cast<void *>(p), 0, sizeof(*p));
+  p->ctx = ctx;
+  AADApiResult rc = AADHip_EncodePlanCreate(ctx, parameter, num_streams, streams, &p->encode);
+  if (rc == AAD_APIRESULT_OK) {
+    /* the decoder sees exactly the images the encoder writes */
+    AADHeaderInfo h;
+    std::vector<AADHipStreamDesc> images(streams, streams + num_streams);
+    std::vector<uint64_t> prefix((size_t)num_streams + 1);
+    uint64_t segments = 0;
+    (void)AADFormat_ParameterToHeader(parameter, 1, AAD_HIP_MAX_NUM_CHANNELS, &h);
+    for (uint32_t i = 0; i < num_streams; i++) {
+      h.num_samples = streams[i].num_samples;
+      images[i].data_size = AADFormat_EncodedSize(&h);
+      prefix[i] = segments;
+      segments += ((uint64_t)streams[i].num_samples * h.num_channels + aad::kCompareSegment - 1) / aad::kCompareSegment;
+    }
+    prefix[num_streams] = segments;
+    rc = AADHip_DecodePlanCreate(ctx, &h, 1, num_streams, images.data(), &p->decode);
+    if (rc == AAD_APIRESULT_OK) {
+      DeviceGuard guard(ctx);
+      if (!guard.ok || !upload(ctx, &p->d_segment_prefix, prefix.data(), prefix.size()) ||
+          !hip_ok(ctx, hipMalloc((void **)&p->d_partials, sizeof(aad::ErrorPartial) * (segments ? segments : 1)), "hipMalloc partials"))
+        rc = AAD_APIRESULT_NG;
+    }
+    p->args.streams = p->decode ? p->decode->d_streams : nullptr;
+    p->args.segment_prefix = p->d_segment_prefix;
+    p->args.total_segments = segments;
+    p->args.num_streams = num_streams;
+    p->args.channels = h.num_channels;
+  }
+  if (rc != AAD_APIRESULT_OK) {
+    AADHip_ReconstructPlanDestroy(p);
+    return rc;
+  }
+  *plan = p;
+  return AAD_APIRESULT_OK;
+}
+
+void AADHip_ReconstructPlanDestroy(struct AADHipReconstructPlan *plan)
+{
+  if (plan == nullptr) return;
+  AADHip_EncodePlanDestroy(plan->encode); /* each synchronises the stream first */
+  AADHip_DecodePlanDestroy(plan->decode);
+  {
+    DeviceGuard guard(plan->ctx);
+    if (guard.ok) {
+      (void)hipStreamSynchronize(plan->ctx->stream);
+      if (plan->d_segment_prefix) (void)hipFree(plan->d_segment_prefix);
+      if (plan->d_partials) (void)hipFree(plan->d_partials);
+    }
+  }
+  delete plan;
+}
+
+AADApiResult AADHip_ReconstructPlanRun(struct AADHipReconstructPlan *plan, const int16_t *device_pcm, uint8_t *device_data,
+                                       int16_t *device_out, int32_t output_kind, struct AADHipErrorStats *device_stats)
+{
+  if (plan == nullptr || device_pcm == nullptr || device_data == nullptr || device_out == nullptr ||
+      device_out == device_pcm)
+    return AAD_APIRESULT_INVALID_ARGUMENT;
+  if (output_kind != AAD_HIP_RECONSTRUCT_DECODED && output_kind != AAD_HIP_RECONSTRUCT_RESIDUAL)
+    return AAD_APIRESULT_INVALID_ARGUMENT;
+  AADHipContext *ctx = plan->ctx;
+  if (plan->args.num_streams == 0) return AAD_APIRESULT_OK;
+  AADApiResult rc = AADHip_EncodePlanRun(plan->encode, device_pcm, device_data, nullptr);
+  if (rc != AAD_APIRESULT_OK) return rc;
+  rc = AADHip_DecodePlanRun(plan->decode, device_data, device_out);
+  if (rc != AAD_APIRESULT_OK) return rc;
+  if (device_stats == nullptr && output_kind == AAD_HIP_RECONSTRUCT_DECODED) return AAD_APIRESULT_OK;
+  DeviceGuard guard(ctx);
+  if (!guard.ok) return AAD_APIRESULT_NG;
+  aad::CompareArgs a = plan->args;
+  a.original = device_pcm;
+  a.decoded = device_out;
+  a.partials = device_stats ? plan->d_partials : nullptr;
+  a.stats = reinterpret_cast<aad::ErrorStatsRecord *>(device_stats);
+  a.write_residual = output_kind == AAD_HIP_RECONSTRUCT_RESIDUAL;
+  if (a.total_segments > 0x7FFFFFFFull) return AAD_APIRESULT_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(aad::compare_segments_kernel, dim3((unsigned)a.total_segments), dim3(aad::kCompareThreads), 0, ctx->stream, a);
+  if (device_stats)
+    hipLaunchKernelGGL(aad::compare_finish_kernel, dim3(a.num_streams), dim3(64), 0, ctx->stream, a);
+  return hip_ok(ctx, hipGetLastError(), "compare launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+}
+
+AADApiResult AADHip_ReconstructBatch(struct AADHipContext *ctx, const struct AADEncodeParameter *parameter,
+                                     uint32_t num_streams, const int16_t *const *pcm, const uint32_t *num_samples,
+                                     int32_t output_kind, int16_t *const *out_pcm, struct AADHipErrorStats *stats)
+{
+  if (ctx == nullptr || parameter == nullptr || (num_streams != 0 && (pcm == nullptr || num_samples == nullptr)))
+    return AAD_APIRESULT_INVALID_ARGUMENT;
+  if (num_streams == 0) return AAD_APIRESULT_OK;
+  std::vector<AADHipStreamDesc> table(num_streams);
+  uint64_t pcm_elems = 0, data_bytes = 0;
+  const uint32_t ch = parameter->num_channels;
+  for (uint32_t i = 0; i < num_streams; i++) {
+    if (pcm[i] == nullptr || (out_pcm != nullptr && out_pcm[i] == nullptr)) return AAD_APIRESULT_INVALID_ARGUMENT;
+    const uint64_t size = AADHip_CalculateEncodedSize(parameter, num_samples[i]);
+    if (size == 0) return AAD_APIRESULT_INVALID_FORMAT;
+    table[i].pcm_offset = pcm_elems;
+    table[i].data_offset = data_bytes;
+    table[i].data_size = size;
+    table[i].num_samples = num_samples[i];
+    table[i].reserved = 0;
+    pcm_elems += round_up((uint64_t)num_samples[i] * ch, 8);
+    data_bytes += round_up(size, 16);
+  }
+  AADHipReconstructPlan *plan = nullptr;
+  AADApiResult rc = AADHip_ReconstructPlanCreate(ctx, parameter, num_streams, table.data(), &plan);
+  if (rc != AAD_APIRESULT_OK) return rc;
+  DeviceGuard guard(ctx);
+  DeviceBuffer d_stats;
+  const size_t pcm_bytes = pcm_elems * sizeof(int16_t), stats_bytes = sizeof(AADHipErrorStats) * (size_t)num_streams;
+  rc = AAD_APIRESULT_NG;
+  do {
+    if (!guard.ok) break;
+    if (!staging_reserve(ctx, ctx->pcm, pcm_bytes + 64) || !staging_reserve(ctx, ctx->data, data_bytes + 64) ||
+        !staging_reserve(ctx, ctx->pcm_out, pcm_bytes + 64))
+      break;
+    if (stats && !hip_ok(ctx, hipMalloc(&d_stats.p, stats_bytes), "hipMalloc stats")) break;
+    for (uint32_t i = 0; i < num_streams; i++)
+      memcpy((int16_t *)ctx->pcm.host + table[i].pcm_offset, pcm[i], (size_t)num_samples[i] * ch * sizeof(int16_t));
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->pcm.dev, ctx->pcm.host, pcm_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D pcm")) break;
+    rc = AADHip_ReconstructPlanRun(plan, (const int16_t *)ctx->pcm.dev, (uint8_t *)ctx->data.dev, (int16_t *)ctx->pcm_out.dev,
+                                   output_kind, (AADHipErrorStats *)d_stats.p);
+    if (rc != AAD_APIRESULT_OK) break;
+    rc = AAD_APIRESULT_NG;
+    if (out_pcm && !hip_ok(ctx, hipMemcpyAsync(ctx->pcm_out.host, ctx->pcm_out.dev, pcm_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H pcm")) break;
+    if (stats && !hip_ok(ctx, hipMemcpyAsync(stats, d_stats.p, stats_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H stats")) break;
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
+    if (out_pcm)
+      for (uint32_t i = 0; i < num_streams; i++)
+        memcpy(out_pcm[i], (int16_t *)ctx->pcm_out.host + table[i].pcm_offset, (size_t)num_samples[i] * ch * sizeof(int16_t));
+    rc = AAD_APIRESULT_OK;
+  } while (0);
+  AADHip_ReconstructPlanDestroy(plan);
+  return rc;
 }
 
 } /* extern "C" */

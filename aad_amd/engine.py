@@ -8,8 +8,8 @@ import ctypes as C
 
 import numpy as np
 
-from .capi import (AADApiResult, AADHeaderInfo, ApiError, LANE_STATE_DTYPE, STREAM_DESC_DTYPE,
-                   load_library, make_parameter)
+from .capi import (AADApiResult, AADHeaderInfo, ApiError, ERROR_STATS_DTYPE, LANE_STATE_DTYPE,
+                   RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL, STREAM_DESC_DTYPE, load_library, make_parameter)
 
 
 def _check(where, rc):
@@ -141,6 +141,57 @@ class Engine:
         pcm = torch.zeros((data.shape[0], header.num_samples, header.num_channels), dtype=torch.int16, device=data.device)
         plan.run(data, pcm)
         return pcm, header
+
+    # ---- reconstruction modes (the reference CLI's -r / -g / -c, src/main.c:275-503) ----------
+    def reconstruct_uniform(self, pcm, param, residual=False, want_stats=True):
+        """pcm: int16 cuda tensor [streams, samples, channels] -> (out int16 tensor of the same
+        shape, stats float64 tensor [streams, 3] = RMSE, MSD, MaxAE or None).  Encode, decode and
+        the comparison run back to back on the device; the images stay in a scratch tensor."""
+        torch = self.torch
+        streams, samples, ch = pcm.shape
+        assert ch == param.num_channels and pcm.dtype == torch.int16 and pcm.is_contiguous()
+        size = self.encoded_size(param, samples)
+        if size == 0:
+            raise ApiError("AADHip_CalculateEncodedSize", AADApiResult.INVALID_FORMAT)
+        stride = _round_up(size, 16)
+        d = np.zeros(streams, dtype=STREAM_DESC_DTYPE)
+        i = np.arange(streams, dtype=np.uint64)
+        d["pcm_offset"] = i * np.uint64(samples * ch)
+        d["data_offset"] = i * np.uint64(stride)
+        d["data_size"] = stride
+        d["num_samples"] = samples
+        plan = C.c_void_p()
+        _check("AADHip_ReconstructPlanCreate",
+               self.lib.AADHip_ReconstructPlanCreate(self._ctx, C.byref(param), streams, d.ctypes.data, C.byref(plan)))
+        try:
+            images = torch.empty((streams, stride), dtype=torch.uint8, device=pcm.device)
+            out = torch.empty_like(pcm)
+            stats = torch.empty((streams, 3), dtype=torch.float64, device=pcm.device) if want_stats else None
+            cur = self._enter()
+            _check("AADHip_ReconstructPlanRun",
+                   self.lib.AADHip_ReconstructPlanRun(plan, pcm.data_ptr(), images.data_ptr(), out.data_ptr(),
+                                                      RECONSTRUCT_RESIDUAL if residual else RECONSTRUCT_DECODED,
+                                                      stats.data_ptr() if want_stats else None))
+            self._exit(cur)
+        finally:
+            self.lib.AADHip_ReconstructPlanDestroy(plan)  # synchronises the stream first
+        return out, stats
+
+    def reconstruct_host(self, pcm_list, param, residual=False, want_pcm=True, want_stats=True):
+        """pcm_list: int16 arrays [samples, channels] -> (list of int16 arrays or None,
+        ERROR_STATS_DTYPE array [streams] or None) through AADHip_ReconstructBatch."""
+        n = len(pcm_list)
+        pcm_list = [np.ascontiguousarray(p, dtype=np.int16) for p in pcm_list]
+        nsamp = np.array([p.shape[0] for p in pcm_list], dtype=np.uint32)
+        outs = [np.zeros_like(p) for p in pcm_list] if want_pcm else None
+        stats = np.zeros(n, dtype=ERROR_STATS_DTYPE) if want_stats else None
+        pp = (C.c_void_p * n)(*[p.ctypes.data for p in pcm_list])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs]) if want_pcm else None
+        _check("AADHip_ReconstructBatch",
+               self.lib.AADHip_ReconstructBatch(self._ctx, C.byref(param), n, pp, nsamp.ctypes.data,
+                                                RECONSTRUCT_RESIDUAL if residual else RECONSTRUCT_DECODED, op,
+                                                stats.ctypes.data if want_stats else None))
+        return outs, stats
 
     # ---- host-memory batches ----------------------------------------------------------------
     def encode_host(self, pcm_list, param, state=None):

@@ -125,6 +125,49 @@ AADApiResult AADHip_DecodeBatch(
     const uint8_t *const *data, const uint64_t *data_size,
     int16_t *const *pcm, const uint32_t *pcm_capacity_frames, uint32_t *decoded_frames);
 
+/* ---- reconstruction modes: encode -> decode -> residual / statistics, all on the device ------ */
+
+/* What the reference CLI's -r / -g / -c modes compute (src/main.c:275-503) for MANY inputs
+ * without the encoded images or the reconstructed PCM ever leaving HBM.  Per stream:
+ *   images  = AADEncoder_EncodeWhole(pcm)          (src/main.c:319-325)
+ *   out     = AADDecoder_DecodeWhole(images)       (src/main.c:328-332)        -> `aad -r`
+ *   out     = int16 wrap of pcm - out              (src/main.c:419-423)        -> `aad -g`
+ *   stats   = RMSE / MSD / MaxAE as `aad -c` prints them (src/main.c:476-497)  -> `aad -c`
+ */
+enum AADHipReconstructOutput {
+  AAD_HIP_RECONSTRUCT_DECODED = 0, /* out holds the reconstructed PCM */
+  AAD_HIP_RECONSTRUCT_RESIDUAL = 1 /* out holds original minus reconstructed */
+};
+
+/* the three numbers of `aad -c`'s "RMSE:%f MSD:%f MaxAE:%f" line, per stream */
+struct AADHipErrorStats {
+  double rms_error;
+  double mean_abs_error;
+  double max_abs_error;
+};
+
+struct AADHipReconstructPlan;
+
+/* `streams` as for AADHip_EncodePlanCreate: pcm_offset addresses BOTH the input and the output
+ * PCM buffer, data_offset / data_size the scratch buffer that receives the .aad images. */
+AADApiResult AADHip_ReconstructPlanCreate(
+    struct AADHipContext *context, const struct AADEncodeParameter *parameter,
+    uint32_t num_streams, const struct AADHipStreamDesc *streams,
+    struct AADHipReconstructPlan **plan);
+void AADHip_ReconstructPlanDestroy(struct AADHipReconstructPlan *plan);
+
+/* device_stats: NULL, or num_streams records.  Fresh encoders (as the CLI creates per file). */
+AADApiResult AADHip_ReconstructPlanRun(
+    struct AADHipReconstructPlan *plan, const int16_t *device_pcm, uint8_t *device_data,
+    int16_t *device_out, int32_t output_kind, struct AADHipErrorStats *device_stats);
+
+/* host-memory form.  out_pcm: NULL (statistics only - nothing but 24 bytes per stream comes
+ * back over PCIe) or per-stream buffers of num_samples[i] frames; stats: NULL or num_streams. */
+AADApiResult AADHip_ReconstructBatch(
+    struct AADHipContext *context, const struct AADEncodeParameter *parameter,
+    uint32_t num_streams, const int16_t *const *pcm, const uint32_t *num_samples,
+    int32_t output_kind, int16_t *const *out_pcm, struct AADHipErrorStats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -480,3 +480,36 @@ int aado_decode_batch(const uint8_t *data, uint32_t num_streams, size_t stride, 
   }
   return AADO_OK;
 }
+
+/* ---- the CLI's reconstruction statistics (reference src/main.c:396-503) ------------------- */
+
+static int32_t residual32(int16_t x, int16_t y) /* src/main.c:419-423 in the reader's 32-bit domain */
+{
+  return (int32_t)(((uint32_t)(int32_t)x << 16) - ((uint32_t)(int32_t)y << 16));
+}
+
+void aado_residual(const int16_t *x, const int16_t *y, size_t count, int16_t *out)
+{
+  size_t i;
+  for (i = 0; i < count; i++) out[i] = (int16_t)(residual32(x[i], y[i]) >> 16); /* src/wav.c:429 */
+}
+
+void aado_error_stats(const int16_t *x, const int16_t *y, uint32_t num_samples, uint32_t channels,
+                      double out[3])
+{
+  double sq = 0.0, ab = 0.0, mx = 0.0;
+  uint32_t c, n;
+  for (c = 0; c < channels; c++) {
+    for (n = 0; n < num_samples; n++) {
+      const size_t i = (size_t)n * channels + c;
+      const double p1 = (double)residual32(x[i], y[i]) / INT32_MAX; /* src/main.c:483 */
+      const double p2 = (double)y[i] / INT32_MAX;                   /* src/main.c:484 */
+      sq += pow(p1 - p2, 2);
+      ab += fabs(p1 - p2);
+      if (mx < fabs(p1 - p2)) mx = fabs(p1 - p2);
+    }
+  }
+  out[0] = sqrt(sq / ((double)channels * num_samples)); /* src/main.c:493-497 */
+  out[1] = ab / ((double)channels * num_samples);
+  out[2] = mx;
+}

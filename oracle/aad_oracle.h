@@ -109,6 +109,23 @@ int aado_encode_batch(const int16_t *pcm, uint32_t num_streams, uint32_t num_sam
 int aado_decode_batch(const uint8_t *data, uint32_t num_streams, size_t stride, size_t size,
                       int16_t *pcm, uint32_t pcm_frames);
 
+/*
+ * The reference CLI's reconstruction modes (src/main.c:275-503): x = original, y = decode(encode(x)),
+ * both interleaved int16, `count` values in total.
+ *   aado_residual     what `aad -g` writes: the CLI subtracts in the WAV reader's 32-bit domain
+ *                     ((x << 16) - (y << 16), wrapping) and the 16-bit writer keeps the top half
+ *                     (src/wav.c:429), i.e. the int16 wrap of x - y  (src/main.c:419-423).
+ *   aado_error_stats  the three numbers `aad -c` prints as "RMSE:%f MSD:%f MaxAE:%f"
+ *                     (src/main.c:476-497).  As written there, the first operand is the
+ *                     RESIDUAL (the WAV buffer was overwritten at :470-474) scaled by 1/INT32_MAX
+ *                     and the second the decoded int16 value scaled by 1/INT32_MAX without the
+ *                     << 16; the oracle restates that arithmetic literally, in the reference's
+ *                     summation order (channel-major) when channels is given.
+ */
+void aado_residual(const int16_t *x, const int16_t *y, size_t count, int16_t *out);
+void aado_error_stats(const int16_t *x, const int16_t *y, uint32_t num_samples, uint32_t channels,
+                      double out_rmse_msd_maxae[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,3 +43,19 @@ def wav16_bytes(pcm, rate):
     head = b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVE" + b"fmt " + struct.pack(
         "<IHHIIHH", 16, 1, ch, rate, rate * 2 * ch, 2 * ch, 16) + b"data" + struct.pack("<I", len(payload))
     return head + payload
+
+
+def cli_mode_input(case):
+    """Rebuild the WAV input of a tests/golden/cli_modes.json case -> (pcm int16 [n, ch], rate, wav bytes)."""
+    import os as _os
+    src = case["source"]
+    if "fixture" in src:
+        path = _os.path.join(GOLDEN, "ref_fixtures", src["fixture"])
+        pcm, rate = read_wav16(path)
+        data = open(path, "rb").read()
+    else:
+        from aad_amd.synth import synth_pcm
+        pcm, rate = synth_pcm(1, src["samples"], src["channels"], seed=src["seed"], kind=src["kind"])[0], 48000
+        data = wav16_bytes(pcm, rate)
+    assert sha256(data) == case["input_sha256"]
+    return pcm, rate, data

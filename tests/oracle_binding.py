@@ -47,6 +47,10 @@ def lib():
         l.aado_decode_step.restype = C.c_int32
         l.aado_encode_batch.argtypes = [vp, u32, u32, u32, u32, u32, u32, u32, u32, vp, sz]
         l.aado_decode_batch.argtypes = [vp, u32, sz, sz, vp, u32]
+        l.aado_residual.argtypes = [vp, vp, sz, vp]
+        l.aado_residual.restype = None
+        l.aado_error_stats.argtypes = [vp, vp, u32, u32, C.POINTER(C.c_double)]
+        l.aado_error_stats.restype = None
         _lib = l
     return _lib
 
@@ -95,3 +99,26 @@ def decode(data, max_channels=8):
     if rc != 0:
         raise RuntimeError("oracle decode rc=%d" % rc)
     return pcm, hd
+
+
+def residual(x, y):
+    """what `aad -g` writes for original x and reconstruction y (int16 [samples, channels])"""
+    x = np.ascontiguousarray(x, dtype=np.int16)
+    y = np.ascontiguousarray(y, dtype=np.int16)
+    out = np.empty_like(x)
+    lib().aado_residual(x.ctypes.data, y.ctypes.data, x.size, out.ctypes.data)
+    return out
+
+
+def error_stats(x, y):
+    """(RMSE, MSD, MaxAE) exactly as `aad -c` computes them"""
+    x = np.ascontiguousarray(x, dtype=np.int16)
+    y = np.ascontiguousarray(y, dtype=np.int16)
+    out = (C.c_double * 3)()
+    lib().aado_error_stats(x.ctypes.data, y.ctypes.data, x.shape[0], x.shape[1], out)
+    return tuple(out)
+
+
+def stats_line(stats):
+    """the line `aad -c` prints (src/main.c:493-497)"""
+    return "RMSE:%f MSD:%f MaxAE:%f \n" % tuple(stats)

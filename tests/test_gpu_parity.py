@@ -301,7 +301,7 @@ def test_aad_batch_cli_matches_reference_cli_outputs(tmp_path):
     for n in names:
         assert (dec_dir / (n + ".wav")).read_bytes() == open(os.path.join(FIX, n + "_decoded.wav"), "rb").read()
     # other option values against the oracle
-    subprocess.run([cli, "-e", "-b", "3", "-s", "256", "-t", "0", "-m", "1", "-o", str(enc_dir),
+    subprocess.run([cli, "-e", "-b", "3", "-s", "256", "-t", "0", "-m", "-o", str(enc_dir),
                     os.path.join(FIX, "unit_impulse.wav")], check=True)
     pcm, rate = read_wav16(os.path.join(FIX, "unit_impulse.wav"))
     assert (enc_dir / "unit_impulse.aad").read_bytes() == ob.encode(pcm, 3, 256, rate, True, 0)

@@ -9,7 +9,7 @@ import pytest
 
 import oracle_binding as ob
 from aad_amd.synth import synth_pcm
-from helpers import GOLDEN, read_wav16, sha256, wav16_bytes
+from helpers import GOLDEN, cli_mode_input, read_wav16, sha256, wav16_bytes
 
 FIX = os.path.join(GOLDEN, "ref_fixtures")
 MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
@@ -96,3 +96,23 @@ def extract_channel_as_mono(aad, c, mono_max_block_size):
             out += body[(u * ch + c) * ub:(u * ch + c + 1) * ub]
         pos += hd.block_size
     return bytes(out)
+
+
+def _cli_mode_cases():
+    with open(os.path.join(GOLDEN, "cli_modes.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_oracle_reconstruction_modes_match_reference_cli():
+    """N3 oracle pin: encode -> decode -> (reconstructed WAV, residual WAV, `-c` statistics line)
+    restated in oracle/aad_oracle.c against what the compiled reference CLI wrote / printed
+    (tests/golden/make_cli_golden.py; src/main.c:275-503)."""
+    cases = _cli_mode_cases()
+    assert len(cases) >= 60
+    for c in cases:
+        pcm, rate, _ = cli_mode_input(c)
+        image = ob.encode(pcm, c["bits"], 1024, rate, c["ms"], c["trials"])
+        rec, _ = ob.decode(image)
+        assert sha256(wav16_bytes(rec, rate)) == c["reconstructed_sha256"], c
+        assert sha256(wav16_bytes(ob.residual(pcm, rec), rate)) == c["residual_sha256"], c
+        assert ob.stats_line(ob.error_stats(pcm, rec)) == c["stats_line"], c
