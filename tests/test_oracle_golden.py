@@ -116,3 +116,21 @@ def test_oracle_reconstruction_modes_match_reference_cli():
         assert sha256(wav16_bytes(rec, rate)) == c["reconstructed_sha256"], c
         assert sha256(wav16_bytes(ob.residual(pcm, rec), rate)) == c["residual_sha256"], c
         assert ob.stats_line(ob.error_stats(pcm, rec)) == c["stats_line"], c
+
+
+def test_oracle_on_reference_roundtrip_suite():
+    """The reference's own encode->decode suite (test/test_aad_encode_decode.c:283-616: three
+    synthetic inputs x 36 parameter sets, six WAV files incl. two real recordings x bits x block
+    sizes x M/S) through the oracle: its RMSE bounds hold AND every .aad image / decoded PCM equals
+    what the compiled reference produced (tests/golden/roundtrip_suite.json)."""
+    from roundtrip_suite import CASES, suite_input, suite_rmse
+    assert len(CASES) >= 215
+    for c in CASES:
+        pcm, file_bytes = suite_input(c)
+        image = ob.encode(pcm, c["bits"], c["max_block_size"], c["sampling_rate"], c["ms"], c["trials"])
+        dec, _ = ob.decode(image)
+        assert sha256(image) == c["aad_sha256"], c
+        assert sha256(dec.tobytes()) == c["decoded_sha256"], c
+        assert suite_rmse(pcm, dec) < c["rms_epsilon"], c
+        if file_bytes is not None:
+            assert len(image) < file_bytes // 2, c
