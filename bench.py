@@ -53,7 +53,7 @@ def algorithmic_bytes_per_sample(channels, block_size, spb):
     return 2.0 + block_size / float(spb * channels)
 
 
-def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1):
+def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1, want_digests=False):
     """-> dict with wall ms/step (max over ranks) and mean kernel durations from HIP events."""
     streams, samples, ch = pcm.shape
     enc = engine.uniform_encode_plan(param, streams, samples)
@@ -99,9 +99,30 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in timed) / len(timed)
     dec_ms = sum(e[1].elapsed_time(e[2]) for e in timed) / len(timed)
     ok = bool((out == pcm).float().mean() > 0.0)  # touch the result so nothing is elided
+    digests = None
+    if want_digests:  # what the timed steps left in HBM, for the bit-exact flag
+        import hashlib
+        digests = (hashlib.sha256(img[:, :enc.image_size].contiguous().cpu().numpy().tobytes()).hexdigest(),
+                   hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())
     enc.close()
     dec.close()
-    return dict(wall_s=dt, enc_ms=enc_ms, dec_ms=dec_ms, header=header, touched=ok)
+    return dict(wall_s=dt, enc_ms=enc_ms, dec_ms=dec_ms, header=header, touched=ok, digests=digests)
+
+
+def golden_check(digests, streams, blocks, trials, rank):
+    """Compare the bytes the timed steps produced with the hashes the compiled reference gave for
+    the same corpus (tests/golden/manifest.json "corpora", made by tests/golden/make_golden.py).
+    -> True / False, or None when the manifest does not hold this workload."""
+    if digests is None or rank != 0 or blocks != 1:
+        return None
+    try:
+        corpora = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["corpora"]
+    except Exception:
+        return None
+    for c in corpora:
+        if (c["streams"], c["samples"], c["channels"], c["bits"], c["trials"], c["seed"]) == (streams, 992, 2, 4, trials, 1234):
+            return digests[0] == c["aad_concat_sha256"] and digests[1] == c["decoded_concat_sha256"]
+    return None
 
 
 def cpu_baseline(pcm_np, param_kw, budget_s=8.0):
@@ -247,7 +268,7 @@ def main():
     torch.cuda.synchronize()
     # everything timed below is launched on the engine's stream, and the HIP events are recorded on it
     torch.cuda.set_stream(engine.stream)
-    m = measure(engine, torch, dist, pcm, param, args.steps, args.warmup, world, args.event_every)
+    m = measure(engine, torch, dist, pcm, param, args.steps, args.warmup, world, args.event_every, want_digests=True)
     hd = m["header"]
     n_step = args.streams * samples * ch  # channel-samples per direction per rank
     value = 2.0 * n_step * world * args.steps / m["wall_s"] / 1e6
@@ -277,6 +298,7 @@ def main():
             "lanes_decode": args.streams * args.blocks * ch,
             "value_counts": "samples encoded + samples decoded",
         },
+        "bit_exact_vs_reference_golden": golden_check(m["digests"], args.streams, args.blocks, args.trials, rank),
         "encode_msps": round(n_step * world / (m["enc_ms"] * 1e-3) / 1e6, 3),
         "decode_msps": round(n_step * world / (m["dec_ms"] * 1e-3) / 1e6, 3),
         "roofline": {
