@@ -39,7 +39,33 @@
 
 #include "aad_tables_data.h"
 
+#ifndef AAD_DUAL_TRIALS
+#define AAD_DUAL_TRIALS 1 /* 0: keep probe and chain of the trial search on the same lanes (measurement aid) */
+#endif
+
+#ifndef AAD_PHASE_TIMING
+#define AAD_PHASE_TIMING 0 /* 1: thread 0 of the encode kernel logs s_memtime at phase boundaries (measurement builds only) */
+#endif
+
 namespace aad {
+
+#if AAD_PHASE_TIMING
+__device__ uint64_t g_phase_times[512];
+__device__ uint32_t g_phase_count;
+__device__ __forceinline__ void phase_mark(bool who)
+{
+  if (who) {
+    const uint32_t i = g_phase_count;
+    if (i < 512) {
+      g_phase_times[i] = __builtin_amdgcn_s_memtime();
+      g_phase_count = i + 1;
+    }
+  }
+}
+#define AAD_PHASE_MARK(who) phase_mark(who)
+#else
+#define AAD_PHASE_MARK(who) ((void)0)
+#endif
 
 constexpr int kTaps = 4;
 constexpr int kBlockHeaderBytesPerCh = 18;
@@ -287,6 +313,7 @@ struct QuadLane {
   int32_t w, h;    /* this lane's tap */
   int32_t idxb;    /* replicated */
   uint32_t round;  /* 16384 in tap 0, 0 elsewhere: the prediction's rounding term enters the sum once */
+  uint32_t newest; /* all ones in tap 0, 0 elsewhere: where the reconstructed sample enters the history */
   bool tap0;
 };
 
@@ -298,19 +325,28 @@ __device__ __forceinline__ int32_t predict(const QuadLane &Q)
   return (int32_t)s >> 15;
 }
 __device__ __forceinline__ void lms_first(QuadLane &Q, int32_t qd) { Q.w += mad_i24(qd, Q.h, 16384) >> 18; }
+/* History shift.  SELECT: one v_mov_b32_dpp + v_cndmask on a lane mask the compiler keeps in VCC
+ * (decoder: shortest path from the new sample to the next product).  Otherwise a bit-select on a
+ * per-lane VGPR mask (v_and_b32_dpp + v_and_or_b32): the encoder bodies have no spare VCC, there
+ * the select's mask ended up in an SGPR pair in some instantiations (the trial-search kernels),
+ * and those ran every chunk ~24 % slower than the very same code with the mask in VCC. */
+template <bool SELECT = false>
 __device__ __forceinline__ void lms_rest_and_shift(QuadLane &Q, int32_t, int32_t y)
 {
-  const int32_t up = (int32_t)quad_dpp<0x90>((uint32_t)Q.h); /* quad_perm [0,0,1,2]: the next-older tap's sample */
-  Q.h = Q.tap0 ? y : up;
+  const uint32_t up = quad_dpp<0x90>((uint32_t)Q.h); /* quad_perm [0,0,1,2]: the next-older tap's sample */
+  if (SELECT) Q.h = Q.tap0 ? y : (int32_t)up;
+  else Q.h = (int32_t)(((uint32_t)y & Q.newest) | (up & ~Q.newest));
 }
+template <bool SELECT = false>
 __device__ __forceinline__ void lms_and_shift(QuadLane &Q, int32_t qd, int32_t y)
 {
   lms_first(Q, qd);
-  lms_rest_and_shift(Q, qd, y);
+  lms_rest_and_shift<SELECT>(Q, qd, y);
 }
 __device__ __forceinline__ void pin_weights(QuadLane &Q) { pin(Q.w); }
 
 /* full state <-> quad (block boundaries only) */
+template <bool BITMASK = true>
 __device__ __forceinline__ QuadLane to_quad(const Lane &L, uint32_t tap)
 {
   QuadLane Q;
@@ -319,6 +355,8 @@ __device__ __forceinline__ QuadLane to_quad(const Lane &L, uint32_t tap)
   Q.idxb = L.idxb;
   Q.round = tap == 0 ? 16384u : 0u;
   Q.tap0 = tap == 0;
+  Q.newest = tap == 0 ? 0xFFFFFFFFu : 0u;
+  if (BITMASK) pin(Q.newest); /* opaque: keeps the bit-select from being turned back into a v_cndmask */
   return Q;
 }
 __device__ __forceinline__ Lane from_quad(const QuadLane &Q)
@@ -663,7 +701,7 @@ __device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, DecodeCarry &C,
     constexpr int j = decltype(jc)::value;
     const int32_t qd = mad_i24((int32_t)step0, (int32_t)t0.x, (int32_t)t0.y) >> (BITS - 1);
     const int32_t yy = clip16(qd + p);
-    lms_and_shift(L, qd, yy);
+    lms_and_shift<true>(L, qd, yy);
     y[j] = finish(yy);
     uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
     pin(s);
@@ -861,7 +899,9 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, QUAD>(lds);
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   const uint32_t ch = CHF ? CHF : a.channels;
   const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -937,7 +977,8 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
   }
   using S = std::conditional_t<QUAD, QuadLane, Lane>;
   S L;
-  if constexpr (QUAD) L = to_quad(H, tap); else L = H;
+  if constexpr (QUAD) L = to_quad<false>(H, tap); else L = H;
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
   const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
@@ -1005,6 +1046,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
     }
     done = full * kChunk;
   }
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   /* remaining units (all of them when CHF == 0): byte loads, bytes past the stream read as zero */
   {
@@ -1024,6 +1066,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       }
     }
   }
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 }
 
 /* ================================================================================ encode == */
@@ -1219,6 +1262,9 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
     if (full) next.load(xp, ch, c);
     next.touch();
     if constexpr (QUAD) {
+#ifdef AAD_LOOP_PAD_DWORDS /* measurement aid: move the chunk loop relative to an 8 KB boundary */
+      asm volatile("s_branch 1f\n .p2align 13\n .fill %0, 4, 0xbf800000\n 1:" ::"n"(AAD_LOOP_PAD_DWORDS));
+#endif
       /* pipeline carried across chunks: chunk k+1's samples are extracted one chunk early */
       int32_t x[kChunk], xn[kChunk];
       EncodeCarry C;
@@ -1232,18 +1278,22 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         for (int j = 0; j < kChunk; j++) xn[j] = next.get(j, c);
         encode_prime_quad<BITS>(L, C, x[0], lds);
       }
-      for (uint32_t k = 0; k < full; k++) {
+      /* x and xn swap roles every chunk (the loop is unrolled by two) so that the samples of
+       * chunk k+2 are extracted straight into the buffer chunk k has just freed - rotating the
+       * buffers with moves cost 30 instructions per chunk */
+      auto one = [&](uint32_t k, int32_t(&cur)[kChunk], const int32_t(&ahead)[kChunk]) {
         if (k + 2 < full) xp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
         next.load(xp, ch, c);
         uint32_t w[2] = {0, 0};
-        encode_chunk16_quad<BITS, EMIT>(L, C, x, xn[0], lds, w, last_qd, sq);
+        encode_chunk16_quad<BITS, EMIT>(L, C, cur, ahead[0], lds, w, last_qd, sq);
         next.touch();
 #pragma unroll
-        for (int j = 0; j < kChunk; j++) {
-          x[j] = xn[j];
-          xn[j] = next.get(j, c);
-        }
+        for (int j = 0; j < kChunk; j++) cur[j] = next.get(j, c);
         if (EMIT && writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD>(body + (uint64_t)k * kOutStride * ch, w, c);
+      };
+      for (uint32_t k = 0; k < full; k += 2) {
+        one(k, x, xn);
+        if (k + 1 < full) one(k + 1, xn, x);
       }
     } else {
       for (uint32_t k = 0; k < full; k++) {
@@ -1319,18 +1369,69 @@ __device__ __forceinline__ void search_best_lane(S &L, const SampleSource<MS> &s
                                                  uint32_t trials, uint32_t ch, uint32_t c, uint32_t tap, const char *lds)
 {
   const bool have_prev = first >= spb;
-  S best = L, run = L, probe = L;
-  double best_rmse = rmse_pass<BITS, CHF, MS, QUAD>(probe, src, first, n, ch, c, tap, lds);
-  for (uint32_t t = 0; t < trials; t++) {
-    if (have_prev) (void)rmse_pass<BITS, CHF, MS, QUAD>(run, src, first - spb, spb, ch, c, tap, lds);
-    const S cand = run;
-    const double r = rmse_pass<BITS, CHF, MS, QUAD>(run, src, first, n, ch, c, tap, lds);
-    if (best_rmse > r) {
+  S best = L, run = L;
+  double best_rmse = 0.0;
+  /* One call site for every pass (the pipelined chunk bodies exist once in the kernel):
+   * pass 0 is the probe, then per trial [previous block,] current block.  Without a previous
+   * block the probe and trial 0 are the same computation from the same state - equal RMSE, no
+   * strict improvement - so it is run once (first block of every stream: 1 + t passes, not 2 + t). */
+  const uint32_t per_trial = have_prev ? 2u : 1u;
+  const uint32_t passes = have_prev ? 1u + 2u * trials : trials;
+  for (uint32_t p = 0; p < passes; p++) {
+    const bool is_probe = have_prev && p == 0;
+    const bool on_prev = have_prev && p != 0 && ((p - 1u) % per_trial) == 0;
+    S from = is_probe ? L : run;
+    const S before = from;
+    const double r = rmse_pass<BITS, CHF, MS, QUAD>(from, src, on_prev ? first - spb : first, on_prev ? spb : n, ch, c, tap, lds);
+    if (!is_probe) run = from;
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if (is_probe || (!have_prev && p == 0)) {
       best_rmse = r;
-      best = cand;
+    } else if (!on_prev && best_rmse > r) {
+      best_rmse = r;
+      best = before;
     }
   }
   L = best;
+}
+
+/*
+ * The same search with its two independent strands on different lanes ("dual" mapping, used
+ * with the quad mapping, i.e. when lanes are idle anyway).  The reference evaluates
+ *   probe:  RMSE of the current block from the carried state                      (1 pass)
+ *   chain:  trials x ([previous block] + current block), each from where the last ended
+ * one after the other: 2 + 2t passes per block with the final encode.  The probe does not feed
+ * the chain, so a second group of four lanes (role 1) runs it while role 0 runs the chain's
+ * first pass; role 0 then finishes the chain alone, picks the winner exactly as the reference
+ * does (strict >, probe first) and encodes: 1 + 2t passes of latency.  One call site for every
+ * pass keeps the pipelined chunk bodies in the kernel once.
+ */
+template <int BITS, int CHF, bool MS, typename S>
+__device__ __forceinline__ void search_best_lane_dual(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t spb,
+                                                      uint32_t trials, uint32_t ch, uint32_t c, uint32_t tap, uint32_t role,
+                                                      const char *lds)
+{
+  const bool have_prev = first >= spb;
+  const uint32_t chain_passes = trials * (have_prev ? 2u : 1u);
+  S best = L, run = L;
+  double best_rmse = 0.0;
+  for (uint32_t p = 0; p < chain_passes; p++) {
+    const bool on_prev = role == 0 && have_prev && (p & 1u) == 0;
+    const bool active = role == 0 || p == 0;
+    double r = 0.0;
+    S before = run;
+    if (active) r = rmse_pass<BITS, CHF, MS, true>(run, src, on_prev ? first - spb : first, on_prev ? spb : n, ch, c, tap, lds);
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if (p == 0) { /* the probe's figure moves over to the chain's lanes (role 1 sits CHF quads above role 0) */
+      const int from = (int)((threadIdx.x & 63u) + (role == 0 ? 4u * (CHF ? CHF : 1) : 0u));
+      best_rmse = __shfl(r, from, 64);
+    }
+    if (role == 0 && !on_prev && best_rmse > r) {
+      best_rmse = r;
+      best = before;
+    }
+  }
+  L = best; /* role 1 is handed role 0's state again after the block's encode pass */
 }
 
 /*
@@ -1342,14 +1443,22 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, QUAD>(lds);
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   const uint32_t ch = CHF ? CHF : a.channels;
   const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t lane = QUAD ? thread >> 2 : thread; /* index of the (stream, channel) recurrence */
+  /* dual: with trials on the quad mapping every stream owns 2 x CHF quads, laid out
+   * [role 0: ch 0 .. CHF-1][role 1: ch 0 .. CHF-1] so that a stereo pair stays 4 lanes apart */
+  constexpr bool DUAL = QUAD && TRIALS && AAD_DUAL_TRIALS;
+  constexpr uint32_t kQuadsPerStream = DUAL ? 2u * (CHF ? CHF : 1) : 1u;
+  const uint32_t role = DUAL ? (uint32_t)((thread >> 2) % kQuadsPerStream) / (CHF ? CHF : 1) : 0u;
+  const uint64_t lane = DUAL ? (thread >> 2) / kQuadsPerStream * (CHF ? CHF : 1) + (thread >> 2) % (CHF ? CHF : 1)
+                             : (QUAD ? thread >> 2 : thread); /* index of the (stream, channel) recurrence */
   const uint32_t tap = QUAD ? threadIdx.x & 3u : 0u;
-  const bool writer = tap == 0;                      /* quad: all four lanes hold the codes, one stores them */
-  if (lane >= (uint64_t)a.num_streams * ch) return; /* whole quads / stereo pairs leave together */
+  const bool writer = tap == 0 && role == 0;         /* quad: all four lanes hold the codes, one stores them */
+  if (lane >= (uint64_t)a.num_streams * ch) return; /* whole quads / stereo pairs / role groups leave together */
   const uint32_t s = (uint32_t)(lane / ch), c = (uint32_t)(lane % ch);
   const StreamDesc sd = a.uni.enabled ? uniform_stream(a.uni, s) : a.streams[s];
   const SampleSource<MS> src = {a.pcm + sd.pcm_offset, ch, c};
@@ -1381,18 +1490,31 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
   for (uint64_t first = 0; first < total; first += spb, block_off += a.block_size) {
     const uint32_t n = total - first < spb ? (uint32_t)(total - first) : spb;
     S L;
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
     if constexpr (TRIALS) { /* reference src/aad_encoder.c:863-871; a separate instantiation so that the
                              * trial-free kernel does not carry the search's registers */
       if constexpr (QUAD) L = to_quad(F, tap); else L = F;
-      search_best_lane<BITS, CHF, MS, QUAD>(L, src, first, n, spb, a.trials, ch, c, tap, lds);
+      if constexpr (DUAL) search_best_lane_dual<BITS, CHF, MS>(L, src, first, n, spb, a.trials, ch, c, tap, role, lds);
+      else search_best_lane<BITS, CHF, MS, QUAD>(L, src, first, n, spb, a.trials, ch, c, tap, lds);
       if constexpr (QUAD) F = from_quad(L); else F = L;
     }
     seed_history(F, src, first, n);
     write_block_header(F, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh, writer);
     if constexpr (QUAD) L = to_quad(F, tap); else L = F;
     uint8_t *body = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch;
-    (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd);
-    if constexpr (QUAD) F = from_quad(L); else F = L;
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if (role == 0) {
+      (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd);
+      if constexpr (QUAD) F = from_quad(L); else F = L;
+    }
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if constexpr (DUAL) { /* the probe lanes start the next block from the encoder's state */
+      const int from = (int)((threadIdx.x & 63u) - role * 4u * (CHF ? CHF : 1));
+      F.w0 = __shfl(F.w0, from, 64); F.w1 = __shfl(F.w1, from, 64); F.w2 = __shfl(F.w2, from, 64); F.w3 = __shfl(F.w3, from, 64);
+      F.h0 = __shfl(F.h0, from, 64); F.h1 = __shfl(F.h1, from, 64); F.h2 = __shfl(F.h2, from, 64); F.h3 = __shfl(F.h3, from, 64);
+      F.idxb = __shfl(F.idxb, from, 64);
+      last_qd = __shfl(last_qd, from, 64);
+    }
   }
 
   if (a.state && writer) {

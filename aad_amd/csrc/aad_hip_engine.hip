@@ -175,10 +175,11 @@ void launch_encode(const aad::EncodeArgs &a, hipStream_t stream)
 {
   const uint64_t lanes = (uint64_t)a.num_streams * a.channels;
   const bool quad = pick_quad(lanes, a.channels);
-  const uint64_t threads = quad ? lanes * 4 : lanes;
+  /* quad + trials = "dual": a second group of four lanes per recurrence runs the search's probe pass */
+  const uint64_t threads = quad ? lanes * (a.trials && AAD_DUAL_TRIALS ? 8 : 4) : lanes;
   const unsigned wg = pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
-  if (a.trials) {
+  if (a.trials || (AAD_PHASE_TIMING && getenv("AAD_FORCE_TRIALS_KERNEL"))) {
     if (quad) launch_encode_mapped<BITS, true, true>(a, grid, block, stream);
     else launch_encode_mapped<BITS, false, true>(a, grid, block, stream);
   } else {
@@ -757,5 +758,21 @@ AADApiResult AADHip_ReconstructBatch(struct AADHipContext *ctx, const struct AAD
   AADHip_ReconstructPlanDestroy(plan);
   return rc;
 }
+
+#if AAD_PHASE_TIMING
+/* measurement builds only: copy out and reset the phase log of the encode kernel */
+uint32_t AADHipDebug_ReadPhaseTimes(uint64_t *out, uint32_t capacity)
+{
+  uint32_t n = 0, zero = 0;
+  uint64_t host[512];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(aad::g_phase_count), sizeof(n));
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(aad::g_phase_times), sizeof(host));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(aad::g_phase_count), &zero, sizeof(zero));
+  if (n > capacity) n = capacity;
+  memcpy(out, host, sizeof(uint64_t) * n);
+  return n;
+}
+#endif
 
 } /* extern "C" */
