@@ -14,6 +14,7 @@
 
 #include "../../include/aad_hip.h"
 #include "aad_compare.hip.h"
+#include "aad_decode_split.hip.h"
 #include "aad_device.hip.h"
 #include "aad_format.h"
 #include "aad_hip_internal.h"
@@ -49,6 +50,8 @@ struct AADHipDecodePlan {
   aad::DecodeArgs args;
   aad::StreamDesc *d_streams;
   uint64_t *d_prefix;
+  int32_t *d_residual; /* scratch of the two-kernel decoder, allocated on first use */
+  uint64_t residual_capacity;
 };
 
 struct AADHipReconstructPlan {
@@ -153,7 +156,7 @@ bool pick_quad(uint64_t recurrences, uint32_t channels)
   if (channels > 2) return false;
   const char *e = getenv("AAD_HIP_MAPPING");
   if (e != nullptr && strcmp(e, "dense") == 0) return false;
-  if (e != nullptr && strcmp(e, "quad") == 0) return true;
+  if (e != nullptr && (strcmp(e, "quad") == 0 || strcmp(e, "quad-fused") == 0)) return true;
   return recurrences * 4 <= 2ull * 1024ull * 64ull;
 }
 
@@ -201,9 +204,48 @@ void launch_decode_mapped(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipSt
     hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false, false>), grid, block, 0, stream, a);
 }
 
-template <int BITS>
-void launch_decode(const aad::DecodeArgs &a, hipStream_t stream)
+/* Quad decode runs its two strands on different lanes (aad_decode_split.hip.h) unless
+ * AAD_HIP_MAPPING=quad-fused asks for the one-lane-does-both kernel or the residual scratch would be
+ * unreasonably large. */
+constexpr uint64_t kMaxResidualBytes = 1ull << 30;
+
+bool want_split_decode(const aad::DecodeArgs &a, uint64_t *bytes, uint32_t *stride)
 {
+  const uint64_t recurrences = a.total_blocks * a.channels;
+  if (!pick_quad(recurrences, a.channels)) return false;
+  const char *e = getenv("AAD_HIP_MAPPING");
+  if (e != nullptr && strcmp(e, "quad-fused") == 0) return false;
+  const uint32_t coded = a.samples_per_block > 4 ? a.samples_per_block - 4 : 0;
+  *stride = (coded + 15u) / 16u * 16u + 16u;
+  *bytes = recurrences * (uint64_t)*stride * sizeof(int32_t);
+  return *bytes <= kMaxResidualBytes;
+}
+
+template <int BITS>
+void launch_decode_split(const aad::DecodeArgs &a, int32_t *residual, uint32_t stride, hipStream_t stream)
+{
+  aad::SplitDecodeArgs sa;
+  sa.d = a;
+  sa.residual = residual;
+  sa.residual_stride = stride;
+  sa.reserved = 0;
+  const uint64_t recurrences = a.total_blocks * a.channels;
+  const dim3 grid((unsigned)((recurrences + 15) / 16)), block(1024); /* 16 recurrences per workgroup */
+  if (a.channels == 1)
+    hipLaunchKernelGGL((aad::decode_split_kernel<BITS, 1, false>), grid, block, 0, stream, sa);
+  else if (a.mid_side)
+    hipLaunchKernelGGL((aad::decode_split_kernel<BITS, 2, true>), grid, block, 0, stream, sa);
+  else
+    hipLaunchKernelGGL((aad::decode_split_kernel<BITS, 2, false>), grid, block, 0, stream, sa);
+}
+
+template <int BITS>
+void launch_decode(const aad::DecodeArgs &a, hipStream_t stream, int32_t *residual, uint32_t residual_stride)
+{
+  if (residual != nullptr) {
+    launch_decode_split<BITS>(a, residual, residual_stride, stream);
+    return;
+  }
   const uint64_t lanes = a.total_blocks * a.channels;
   const bool quad = pick_quad(lanes, a.channels);
   const uint64_t threads = quad ? lanes * 4 : lanes;
@@ -406,6 +448,8 @@ AADApiResult AADHip_DecodePlanCreate(struct AADHipContext *ctx, const struct AAD
   p->ctx = ctx;
   p->d_streams = nullptr;
   p->d_prefix = nullptr;
+  p->d_residual = nullptr;
+  p->residual_capacity = 0;
   DeviceGuard guard(ctx);
   if (!guard.ok || !upload(ctx, &p->d_streams, reinterpret_cast<const aad::StreamDesc *>(streams), num_streams) ||
       !upload(ctx, &p->d_prefix, prefix.data(), prefix.size())) {
@@ -442,6 +486,7 @@ void AADHip_DecodePlanDestroy(struct AADHipDecodePlan *plan)
     (void)hipStreamSynchronize(plan->ctx->stream);
     (void)hipFree(plan->d_streams);
     (void)hipFree(plan->d_prefix);
+    if (plan->d_residual) (void)hipFree(plan->d_residual);
   }
   delete plan;
 }
@@ -456,10 +501,26 @@ AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *
   aad::DecodeArgs a = plan->args;
   a.data = device_data;
   a.pcm = device_pcm;
+  uint64_t residual_bytes = 0;
+  uint32_t residual_stride = 0;
+  int32_t *residual = nullptr;
+  if (want_split_decode(a, &residual_bytes, &residual_stride)) {
+    if (plan->residual_capacity < residual_bytes) { /* first quad run of this plan */
+      if (plan->d_residual) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(plan->d_residual);
+        plan->d_residual = nullptr;
+        plan->residual_capacity = 0;
+      }
+      if (!hip_ok(ctx, hipMalloc((void **)&plan->d_residual, residual_bytes), "hipMalloc residual scratch")) return AAD_APIRESULT_NG;
+      plan->residual_capacity = residual_bytes;
+    }
+    residual = plan->d_residual;
+  }
   switch (a.bits) {
-    case 4: launch_decode<4>(a, ctx->stream); break;
-    case 3: launch_decode<3>(a, ctx->stream); break;
-    case 2: launch_decode<2>(a, ctx->stream); break;
+    case 4: launch_decode<4>(a, ctx->stream, residual, residual_stride); break;
+    case 3: launch_decode<3>(a, ctx->stream, residual, residual_stride); break;
+    case 2: launch_decode<2>(a, ctx->stream, residual, residual_stride); break;
     default: return AAD_APIRESULT_INVALID_FORMAT;
   }
   return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;

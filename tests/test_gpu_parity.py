@@ -30,9 +30,10 @@ def engine():
     e.close()
 
 
-@pytest.fixture(params=["dense", "quad"])
+@pytest.fixture(params=["dense", "quad", "quad-fused"])
 def mapping(request):
-    """Both lane mappings of the kernels (one lane per recurrence / four lanes per recurrence):
+    """The lane mappings of the kernels (one lane per recurrence / four lanes per recurrence; for the
+    quad decoder both the two-kernel form and the single fused kernel):
     the host picks by batch size, AAD_HIP_MAPPING forces one (read at every launch)."""
     os.environ["AAD_HIP_MAPPING"] = request.param
     yield request.param
