@@ -187,7 +187,7 @@ struct Pack {
 };
 
 /* stage the tables into LDS; every thread of the workgroup must call this */
-template <int BITS, bool QUAD>
+template <int BITS, bool QUAD, int WIDE_STEP_SHIFT = 0>
 __device__ __forceinline__ void stage_tables(char *lds)
 {
   constexpr int kShift = BITS - 1;
@@ -199,7 +199,7 @@ __device__ __forceinline__ void stage_tables(char *lds)
     reinterpret_cast<float *>(lds + kLdsHsOff)[i] = hs;
     if (QUAD) {
       u32x4 e;
-      e.x = c_step_table[i];
+      e.x = (uint32_t)c_step_table[i] << WIDE_STEP_SHIFT; /* the quad encoder wants 2 * step, see encode_chunk16_quad */
       e.y = __float_as_uint(hr);
       e.z = __float_as_uint(hs);
       e.w = 0;
@@ -548,13 +548,15 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     /* A */
     const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)),
                              Pack<BITS>::kMagMax);
-    const uint32_t step_j = e.x;
+    const uint32_t step2_j = e.x; /* 2 * step (stage_tables<.., WIDE_STEP_SHIFT = 1>) */
     L.idxb = clamp_idx(L.idxb + index_delta_arith<BITS>(mag));
     e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
     __builtin_amdgcn_sched_barrier(0);
-    /* B */
-    const uint32_t m21 = (mag << 1) | 1u;
-    const int32_t q = (int32_t)(__umul24(step_j, m21) >> (BITS - 1));
+    /* B: q = (step * (2 mag + 1)) >> (BITS-1) as ONE high multiply:
+     * (2 step) * ((2 mag + 1) << (32 - BITS)) = step * (2 mag + 1) * 2^(33 - BITS), upper 32 bits.
+     * 2 step < 2^16 and (2 mag + 1) < 2^BITS, so neither factor overflows and the result is exact. */
+    const uint32_t m21s = (mag << (33 - BITS)) | (1u << (32 - BITS));
+    const int32_t q = (int32_t)__umulhi(step2_j, m21s);
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
     lms_and_shift(L, qd, y);
@@ -1444,7 +1446,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
-  stage_tables<BITS, QUAD>(lds);
+  stage_tables<BITS, QUAD, 1>(lds);
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   const uint32_t ch = CHF ? CHF : a.channels;
