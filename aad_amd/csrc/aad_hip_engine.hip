@@ -209,16 +209,31 @@ void launch_decode_mapped(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipSt
  * unreasonably large. */
 constexpr uint64_t kMaxResidualBytes = 1ull << 30;
 
+/* Decode mapping by batch size (tools/decode_crossover.py, one-block stereo streams on MI355X):
+ * the split quad decoder wins up to ~8 k recurrences (one or two 16-wave workgroups per CU), the
+ * fused quad kernel from there to ~20 k, the dense mapping beyond.  AAD_HIP_MAPPING forces one. */
+enum class DecodeMapping { Dense, QuadFused, QuadSplit };
+
+DecodeMapping pick_decode_mapping(uint64_t recurrences, uint32_t channels)
+{
+  if (channels > 2) return DecodeMapping::Dense;
+  const char *e = getenv("AAD_HIP_MAPPING");
+  if (e != nullptr && strcmp(e, "dense") == 0) return DecodeMapping::Dense;
+  if (e != nullptr && strcmp(e, "quad-fused") == 0) return DecodeMapping::QuadFused;
+  if (e != nullptr && strcmp(e, "quad") == 0) return DecodeMapping::QuadSplit;
+  if (recurrences <= 8192) return DecodeMapping::QuadSplit;
+  if (recurrences <= 20480) return DecodeMapping::QuadFused;
+  return DecodeMapping::Dense;
+}
+
 bool want_split_decode(const aad::DecodeArgs &a, uint64_t *bytes, uint32_t *stride)
 {
   const uint64_t recurrences = a.total_blocks * a.channels;
-  if (!pick_quad(recurrences, a.channels)) return false;
-  const char *e = getenv("AAD_HIP_MAPPING");
-  if (e != nullptr && strcmp(e, "quad-fused") == 0) return false;
+  if (pick_decode_mapping(recurrences, a.channels) != DecodeMapping::QuadSplit) return false;
   const uint32_t coded = a.samples_per_block > 4 ? a.samples_per_block - 4 : 0;
   *stride = (coded + 15u) / 16u * 16u + 16u;
   *bytes = recurrences * (uint64_t)*stride * sizeof(int32_t);
-  return *bytes <= kMaxResidualBytes;
+  return *bytes <= kMaxResidualBytes; /* else the fused quad kernel */
 }
 
 template <int BITS>
@@ -247,7 +262,7 @@ void launch_decode(const aad::DecodeArgs &a, hipStream_t stream, int32_t *residu
     return;
   }
   const uint64_t lanes = a.total_blocks * a.channels;
-  const bool quad = pick_quad(lanes, a.channels);
+  const bool quad = pick_decode_mapping(lanes, a.channels) != DecodeMapping::Dense;
   const uint64_t threads = quad ? lanes * 4 : lanes;
   const unsigned wg = pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);

@@ -293,7 +293,7 @@ def main():
             "workload": "BASELINE configs[1]+[2]: %d independent 48 kHz stereo 4-bit streams x %d block(s) "
                         "(%d samples/ch) per GPU, encode then decode, device-resident" % (args.streams, args.blocks, samples),
             "streams_per_gpu": args.streams, "samples_per_channel": samples, "channels": ch, "bits_per_sample": bits,
-            "max_block_size": mbs, "num_encode_trials": args.trials, "lane_mapping": os.environ.get("AAD_HIP_MAPPING", "auto (quad for this batch size)"),
+            "max_block_size": mbs, "num_encode_trials": args.trials, "lane_mapping": os.environ.get("AAD_HIP_MAPPING", "auto (quad for this batch size: four lanes per recurrence; decode with the step-index walk as a parallel scan)"),
             "lanes_encode": args.streams * ch,
             "lanes_decode": args.streams * args.blocks * ch,
             "value_counts": "samples encoded + samples decoded",
@@ -308,7 +308,7 @@ def main():
             "algorithmic_bytes_per_launch": int(round(n_step * bps)),
             "bytes_per_sample": round(bps, 4), "samples_per_launch": n_step,
             "kernel_ms": round(m["enc_ms"], 5), "hip_events": "on every %d-th step of the timed region" % args.event_every,
-            "decode_kernel": {"kernel": "aad::decode_blocks_kernel<4>", "achieved": round(dec_gbs, 3),
+            "decode_kernel": {"kernel": "aad::decode_split_kernel<4> (quad batches) / aad::decode_blocks_kernel<4> (dense)", "achieved": round(dec_gbs, 3),
                               "frac": round(dec_gbs / HBM_PEAK_GBS, 6), "kernel_ms": round(m["dec_ms"], 5)},
         },
     }

@@ -15,11 +15,19 @@ import sys
 
 
 def per_kernel(d, counter):
+    """mean counter value per launch of the encode / decode kernels; reads rocprofv3's CSV output
+    or its default rocpd SQLite database, whichever the pass directory holds"""
+    import sqlite3
     agg = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter and "aad::" in r["Kernel_Name"]:
                 agg["encode" if "encode" in r["Kernel_Name"] else "decode"].append(float(r["Counter_Value"]))
+    for f in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+        con = sqlite3.connect(f)
+        for name, cname, value in con.execute("select kernel_name, counter_name, value from counters_collection order by dispatch_id"):
+            if cname == counter and "aad::" in name:
+                agg["encode" if "encode" in name else "decode"].append(float(value))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
