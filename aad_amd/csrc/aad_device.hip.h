@@ -7,25 +7,27 @@
  *   decode: lane = (block, channel)  - every block header reloads the whole state.
  * Adjacent lanes are the channels of one stream/block, so the bytes they touch are adjacent.
  *
- * What bounds these kernels (measured, tools/microbench): a gfx950 wave issues one instruction
- * per ~4.2-5.2 cycles whatever the instruction (VALU, SALU, LDS, 32-bit multiplies included)
- * and every BASELINE workload has far fewer lanes than the chip has SIMD slots.  The lever is
- * therefore the NUMBER of instructions on the per-sample path, not their kind:
+ * What bounds these kernels (measured, tools/microbench, tools/phase_probe.py): every BASELINE
+ * workload has far fewer recurrences than the chip has SIMD slots, and a lone gfx950 wave issues
+ * one instruction per 4 cycles - one more when it reads the result of the instruction just before
+ * it - whatever the instruction (VALU, SALU, LDS; 24- or 32-bit multiplies alike).  The lever is
+ * therefore the NUMBER of instruction slots on the per-sample path, s_nop and s_waitcnt included:
  *   - the whole per-channel state (4 weights, 4 history samples, step index) lives in VGPRs,
  *     history rotation is free because samples are processed in unrolled chunks of 16;
- *   - step size, fl32(0.5/step) and fl32(2^(b-1)*0.5/step) sit in LDS as dense dword arrays
- *     (bank-conflict free), fetched one sample ahead in hand-pipelined 16-sample chunks;
+ *   - step size, fl32(0.5/step) and fl32(2^(b-1)*0.5/step) sit in LDS, fetched one sample ahead
+ *     in hand-pipelined 16-sample chunks;
  *   - the quantiser's integer division is  min(trunc(fma(|d|, hs, hr)), magmax)  - convert, fma
  *     with |.| source modifier, convert, min - proved equal to the reference's division for
  *     every reachable operand (tests/test_quantiser_equiv.py);
- *   - encoder: the step-index delta is one ds_read_i16 addressed by the odd number 2*mag+1 that
- *     the dequantiser needs anyway; decoder: one 12-byte record per code gives the signed
- *     multiplier, the rounding bias and the delta, so dequantising is a mad + a shift;
- *   - predict uses full 32-bit multiplies (exact int32 wraparound for ANY weights; v_mul_lo_u32
- *     issues as fast as the 24-bit forms on gfx950), the LMS products v_mad_i32_i24
- *     (|qd| <= 61438, |h| <= 32768: exact);
+ *   - dequantising is a mad + a shift from a 12-byte per-code record (decoder) or one
+ *     v_mul_hi_u32 (quad encoder); the encoder's step-index delta is a v_perm_b32 byte lookup;
+ *   - predict uses full 32-bit multiplies (exact int32 wraparound for ANY weights), the LMS
+ *     products v_mad_i32_i24 (|qd| <= 61438, |h| <= 32768: exact);
  *   - code bytes are read/written in wide unaligned accesses per 16-sample chunk; the stereo
- *     L/R byte interleave is one DPP lane swap plus v_perm_b32 byte permutes.
+ *     L/R byte interleave is one DPP lane swap plus v_perm_b32 byte permutes;
+ *   - with few recurrences the "quad" mapping spreads each one over four lanes (lane t = tap t);
+ *     the decoder's step-index walk, which is a scan and not a recurrence, then moves to other
+ *     waves altogether (aad_decode_split.hip.h).
  * There is no contraction anywhere, hence no MFMA.
  *
  * Arithmetic widths follow SURVEY.md finding 5: int32 wraparound, arithmetic right shifts.
@@ -1264,9 +1266,6 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
     if (full) next.load(xp, ch, c);
     next.touch();
     if constexpr (QUAD) {
-#ifdef AAD_LOOP_PAD_DWORDS /* measurement aid: move the chunk loop relative to an 8 KB boundary */
-      asm volatile("s_branch 1f\n .p2align 13\n .fill %0, 4, 0xbf800000\n 1:" ::"n"(AAD_LOOP_PAD_DWORDS));
-#endif
       /* pipeline carried across chunks: chunk k+1's samples are extracted one chunk early */
       int32_t x[kChunk], xn[kChunk];
       EncodeCarry C;
