@@ -41,10 +41,6 @@
 
 #include "aad_tables_data.h"
 
-#ifndef AAD_DUAL_TRIALS
-#define AAD_DUAL_TRIALS 1 /* 0: keep probe and chain of the trial search on the same lanes (measurement aid) */
-#endif
-
 #ifndef AAD_PHASE_TIMING
 #define AAD_PHASE_TIMING 0 /* 1: thread 0 of the encode kernel logs s_memtime at phase boundaries (measurement builds only) */
 #endif
@@ -1439,10 +1435,11 @@ __device__ __forceinline__ void search_best_lane_dual(S &L, const SampleSource<M
  * Stream-parallel encode (reference src/aad_encoder.c:814-891 with EncodeBlock :565-727 and the
  * optional trial search :470-562 inlined).  lane = (stream, channel).
  */
-template <int BITS, int CHF, bool MS, bool QUAD, bool TRIALS>
+template <int BITS, int CHF, bool MS, bool QUAD, bool TRIALS, bool DUAL = false>
 __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
+  static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
   __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, QUAD, 1>(lds);
@@ -1452,7 +1449,6 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
   const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   /* dual: with trials on the quad mapping every stream owns 2 x CHF quads, laid out
    * [role 0: ch 0 .. CHF-1][role 1: ch 0 .. CHF-1] so that a stereo pair stays 4 lanes apart */
-  constexpr bool DUAL = QUAD && TRIALS && AAD_DUAL_TRIALS;
   constexpr uint32_t kQuadsPerStream = DUAL ? 2u * (CHF ? CHF : 1) : 1u;
   const uint32_t role = DUAL ? (uint32_t)((thread >> 2) % kQuadsPerStream) / (CHF ? CHF : 1) : 0u;
   const uint64_t lane = DUAL ? (thread >> 2) / kQuadsPerStream * (CHF ? CHF : 1) + (thread >> 2) % (CHF ? CHF : 1)

@@ -43,6 +43,7 @@ struct AADHipEncodePlan {
   AADHipContext *ctx;
   aad::EncodeArgs args;
   aad::StreamDesc *d_streams;
+  uint64_t mean_blocks_per_stream;
 };
 
 struct AADHipDecodePlan {
@@ -160,34 +161,47 @@ bool pick_quad(uint64_t recurrences, uint32_t channels)
   return recurrences * 4 <= 2ull * 1024ull * 64ull;
 }
 
-template <int BITS, bool QUAD, bool TRIALS>
+template <int BITS, bool QUAD, bool TRIALS, bool DUAL>
 void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
 {
   if (a.channels == 1)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD, TRIALS>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD, TRIALS, DUAL>), grid, block, 0, stream, a);
   else if (a.channels == 2 && a.mid_side)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD, TRIALS>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD, TRIALS, DUAL>), grid, block, 0, stream, a);
   else if (a.channels == 2)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD, TRIALS>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD, TRIALS, DUAL>), grid, block, 0, stream, a);
   else if constexpr (!QUAD)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS, false>), grid, block, 0, stream, a);
+}
+
+/* The trial search's probe strand gets lanes of its own ("dual") only where that pays: a masked
+ * half-wave runs the chain's later passes ~10 % slower, and for the first block of a stream there
+ * is no separate probe to overlap - so streams of three blocks and more (tools/phase_probe.py). */
+bool pick_dual(const aad::EncodeArgs &a, bool quad, uint64_t mean_blocks_per_stream)
+{
+  if (!quad || a.trials == 0) return false;
+  const char *e = getenv("AAD_HIP_TRIAL_LANES");
+  if (e != nullptr && strcmp(e, "dual") == 0) return true;
+  if (e != nullptr && strcmp(e, "single") == 0) return false;
+  return mean_blocks_per_stream >= 3;
 }
 
 template <int BITS>
-void launch_encode(const aad::EncodeArgs &a, hipStream_t stream)
+void launch_encode(const aad::EncodeArgs &a, hipStream_t stream, uint64_t mean_blocks_per_stream)
 {
   const uint64_t lanes = (uint64_t)a.num_streams * a.channels;
   const bool quad = pick_quad(lanes, a.channels);
-  /* quad + trials = "dual": a second group of four lanes per recurrence runs the search's probe pass */
-  const uint64_t threads = quad ? lanes * (a.trials && AAD_DUAL_TRIALS ? 8 : 4) : lanes;
+  const bool dual = pick_dual(a, quad, mean_blocks_per_stream);
+  const uint64_t threads = quad ? lanes * (dual ? 8 : 4) : lanes;
   const unsigned wg = pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
-  if (a.trials || (AAD_PHASE_TIMING && getenv("AAD_FORCE_TRIALS_KERNEL"))) {
-    if (quad) launch_encode_mapped<BITS, true, true>(a, grid, block, stream);
-    else launch_encode_mapped<BITS, false, true>(a, grid, block, stream);
+  if (a.trials) {
+    if (dual) launch_encode_mapped<BITS, true, true, true>(a, grid, block, stream);
+    else if (quad) launch_encode_mapped<BITS, true, true, false>(a, grid, block, stream);
+    else launch_encode_mapped<BITS, false, true, false>(a, grid, block, stream);
   } else {
-    if (quad) launch_encode_mapped<BITS, true, false>(a, grid, block, stream);
-    else launch_encode_mapped<BITS, false, false>(a, grid, block, stream);
+    if (quad) launch_encode_mapped<BITS, true, false, false>(a, grid, block, stream);
+    else launch_encode_mapped<BITS, false, false, false>(a, grid, block, stream);
   }
 }
 
@@ -361,16 +375,19 @@ AADApiResult AADHip_EncodePlanCreate(struct AADHipContext *ctx, const struct AAD
   /* what AADEncoder_EncodeHeader would reject (bits == 1, zero rate, M/S on mono, ...) */
   if (!AADFormat_HeaderFieldsValid(&h, AAD_HIP_MAX_NUM_CHANNELS)) return AAD_APIRESULT_INVALID_FORMAT;
   if (h.ch_process_method == AAD_CH_PROCESS_METHOD_MS && h.num_channels != 2) return AAD_APIRESULT_INVALID_FORMAT;
+  uint64_t total_blocks = 0;
   for (uint32_t i = 0; i < num_streams; i++) {
     if (streams[i].num_samples == 0) return AAD_APIRESULT_INVALID_FORMAT; /* src/aad_encoder.c:157-159 */
     h.num_samples = streams[i].num_samples;
     if (streams[i].data_size < AADFormat_EncodedSize(&h)) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
+    total_blocks += ((uint64_t)streams[i].num_samples + h.num_samples_per_block - 1) / h.num_samples_per_block;
   }
 
   AADHipEncodePlan *p = new (std::nothrow) AADHipEncodePlan();
   if (p == nullptr) return AAD_APIRESULT_NG;
   p->ctx = ctx;
   p->d_streams = nullptr;
+  p->mean_blocks_per_stream = num_streams ? total_blocks / num_streams : 0;
   DeviceGuard guard(ctx);
   if (!guard.ok || !upload(ctx, &p->d_streams, reinterpret_cast<const aad::StreamDesc *>(streams), num_streams)) {
     if (p->d_streams) (void)hipFree(p->d_streams);
@@ -417,9 +434,9 @@ AADApiResult AADHip_EncodePlanRun(struct AADHipEncodePlan *plan, const int16_t *
   a.data = device_data;
   a.state = reinterpret_cast<aad::LaneStateRecord *>(device_state);
   switch (a.bits) {
-    case 4: launch_encode<4>(a, ctx->stream); break;
-    case 3: launch_encode<3>(a, ctx->stream); break;
-    case 2: launch_encode<2>(a, ctx->stream); break;
+    case 4: launch_encode<4>(a, ctx->stream, plan->mean_blocks_per_stream); break;
+    case 3: launch_encode<3>(a, ctx->stream, plan->mean_blocks_per_stream); break;
+    case 2: launch_encode<2>(a, ctx->stream, plan->mean_blocks_per_stream); break;
     default: return AAD_APIRESULT_INVALID_FORMAT;
   }
   return hip_ok(ctx, hipGetLastError(), "encode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;

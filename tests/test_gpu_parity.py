@@ -74,6 +74,29 @@ def test_manifest_cases_batched(engine, mapping):
             assert sha256(d.tobytes()) == c["decoded_sha256"], c["name"]
 
 
+@pytest.mark.parametrize("lanes", ["dual", "single"])
+def test_trial_search_lane_layouts(engine, lanes):
+    """The trial search on the quad mapping with its probe strand on lanes of its own ("dual", the
+    host's choice for streams of three blocks and more) and on the chain's lanes ("single"): every
+    golden case with trials, single- and many-block streams alike, under both."""
+    os.environ["AAD_HIP_MAPPING"] = "quad"
+    os.environ["AAD_HIP_TRIAL_LANES"] = lanes
+    try:
+        groups = {}
+        for c in MANIFEST["cases"]:
+            if c["trials"]:
+                groups.setdefault((c["channels"], c["bits"], c["ms"], c["trials"], c["max_block_size"]), []).append(c)
+        assert len(groups) >= 30
+        for (ch, bits, ms, trials, mbs), cases in groups.items():
+            pcms = [synth_pcm(1, c["samples"], ch, seed=c["seed"], kind=c["kind"])[0] for c in cases]
+            images = engine.encode_host(pcms, make_parameter(ch, bits, mbs, 48000, ms, trials))
+            for c, img in zip(cases, images):
+                assert sha256(img) == c["aad_sha256"], (lanes, c["name"])
+    finally:
+        os.environ.pop("AAD_HIP_MAPPING", None)
+        os.environ.pop("AAD_HIP_TRIAL_LANES", None)
+
+
 @pytest.mark.parametrize("corpus", MANIFEST["corpora"], ids=lambda c: c["name"])
 def test_baseline_corpora_device_resident(engine, corpus, mapping):
     """BASELINE configs 2/3/4(stereo)/5 shapes: device-resident uniform batches, hashed against the reference."""
