@@ -342,16 +342,25 @@ __device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint6
       if (k + 2 < full) one(k + 2, b2, b0, b1);
     }
   }
-  /* what is left of the block (fewer than 16 samples), one at a time; C.p is already the
-   * prediction for the next sample but its pipelined extras belong to a residual never used */
+  /* What is left of the block (fewer than 16 samples), one at a time.  The residuals are fetched
+   * with the same four wide loads first (the scratch rows are padded by a chunk): a load per
+   * iteration would put a memory round trip on every one of these last samples. */
   int32_t p = full ? C.p : predict(L);
-  for (uint32_t i = full * kChunk; i < coded; i++) {
-    const int32_t qd = res[i];
-    const int32_t yy = clip16(qd + p);
-    lms_and_shift<true>(L, qd, yy);
-    p = predict(L);
-    const int32_t yo = finish(yy);
-    if (writer) dst[(uint64_t)(kTaps + i) * ch] = (int16_t)yo;
+  const uint32_t rem = coded - full * kChunk;
+  if (rem) {
+    ChunkResiduals last;
+    last.load(res + full * kChunk);
+    static_for<0, kChunk - 1>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if ((uint32_t)j < rem) {
+        const int32_t qd = last.get(j);
+        const int32_t yy = clip16(qd + p);
+        lms_and_shift<true>(L, qd, yy);
+        p = predict(L);
+        const int32_t yo = finish(yy);
+        if (writer) dst[(uint64_t)(kTaps + full * kChunk + j) * ch] = (int16_t)yo;
+      }
+    });
   }
 }
 
