@@ -48,8 +48,8 @@
 namespace aad {
 
 #if AAD_PHASE_TIMING
-__device__ uint64_t g_phase_times[512];
-__device__ uint32_t g_phase_count;
+static __device__ uint64_t g_phase_times[512]; /* per translation unit: the reader in aad_hip_engine.hip sees that unit's kernels only */
+static __device__ uint32_t g_phase_count;
 __device__ __forceinline__ void phase_mark(bool who)
 {
   if (who) {
@@ -99,11 +99,12 @@ __device__ __forceinline__ uint32_t wide_addr(int32_t idxb) { return (uint32_t)i
 /* byte offset of the step index's slot in the dword arrays */
 __device__ __forceinline__ uint32_t slot_addr(int32_t idxb) { return ((uint32_t)idxb >> 2) & 0x3FCu; }
 
-__constant__ uint16_t c_step_table[AAD_STEP_TABLE_LEN] = {AAD_STEP_TABLE_VALUES};
-__constant__ uint32_t c_half_recip_bits[AAD_STEP_TABLE_LEN] = {AAD_HALF_RECIP_BITS};
-__constant__ int16_t c_delta4[8] = {AAD_INDEX_DELTA_4BIT};
-__constant__ int16_t c_delta3[4] = {AAD_INDEX_DELTA_3BIT};
-__constant__ int16_t c_delta2[2] = {AAD_INDEX_DELTA_2BIT};
+/* internal linkage: the header is compiled into more than one translation unit */
+static __constant__ uint16_t c_step_table[AAD_STEP_TABLE_LEN] = {AAD_STEP_TABLE_VALUES};
+static __constant__ uint32_t c_half_recip_bits[AAD_STEP_TABLE_LEN] = {AAD_HALF_RECIP_BITS};
+static __constant__ int16_t c_delta4[8] = {AAD_INDEX_DELTA_4BIT};
+static __constant__ int16_t c_delta3[4] = {AAD_INDEX_DELTA_3BIT};
+static __constant__ int16_t c_delta2[2] = {AAD_INDEX_DELTA_2BIT};
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));

@@ -14,7 +14,7 @@
 
 #include "../../include/aad_hip.h"
 #include "aad_compare.hip.h"
-#include "aad_decode_split.hip.h"
+#include "aad_decode_split_launch.h"
 #include "aad_device.hip.h"
 #include "aad_format.h"
 #include "aad_hip_internal.h"
@@ -251,30 +251,9 @@ bool want_split_decode(const aad::DecodeArgs &a, uint64_t *bytes, uint32_t *stri
 }
 
 template <int BITS>
-void launch_decode_split(const aad::DecodeArgs &a, int32_t *residual, uint32_t stride, hipStream_t stream)
-{
-  aad::SplitDecodeArgs sa;
-  sa.d = a;
-  sa.residual = residual;
-  sa.residual_stride = stride;
-  sa.reserved = 0;
-  const uint64_t recurrences = a.total_blocks * a.channels;
-  const dim3 grid((unsigned)((recurrences + 15) / 16)), block(1024); /* 16 recurrences per workgroup */
-  if (a.channels == 1)
-    hipLaunchKernelGGL((aad::decode_split_kernel<BITS, 1, false>), grid, block, 0, stream, sa);
-  else if (a.mid_side)
-    hipLaunchKernelGGL((aad::decode_split_kernel<BITS, 2, true>), grid, block, 0, stream, sa);
-  else
-    hipLaunchKernelGGL((aad::decode_split_kernel<BITS, 2, false>), grid, block, 0, stream, sa);
-}
-
-template <int BITS>
 void launch_decode(const aad::DecodeArgs &a, hipStream_t stream, int32_t *residual, uint32_t residual_stride)
 {
-  if (residual != nullptr) {
-    launch_decode_split<BITS>(a, residual, residual_stride, stream);
-    return;
-  }
+  if (residual != nullptr && aad::launch_decode_split(a, residual, residual_stride, stream)) return;
   const uint64_t lanes = a.total_blocks * a.channels;
   const bool quad = pick_decode_mapping(lanes, a.channels) != DecodeMapping::Dense;
   const uint64_t threads = quad ? lanes * 4 : lanes;
