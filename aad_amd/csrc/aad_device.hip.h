@@ -535,10 +535,19 @@ __device__ __forceinline__ void encode_prime_quad(QuadLane &L, EncodeCarry &C, i
 
 /* x: this chunk's 16 samples, xn0: the first sample of the next chunk (the pipeline is carried
  * from chunk to chunk like the decoder's, see DecodeCarry) */
-template <int BITS, bool EMIT>
+/* PACKED: x holds the chunk as eight dwords of two int16 samples each (and xn0 the next chunk's
+ * first such dword) instead of sixteen sign-extended values */
+template <int BITS, bool EMIT, bool PACKED = false>
 __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C, const int32_t *x, int32_t xn0,
                                                     const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq)
 {
+  auto sample = [&](int k) -> int32_t { /* sample k of this chunk (k = 16: first of the next), k compile-time */
+    if (PACKED) {
+      const int32_t word = k < kChunk ? x[k >> 1] : xn0;
+      return (k & 1) ? word >> 16 : (int32_t)(int16_t)word;
+    }
+    return k < kChunk ? x[k] : xn0;
+  };
   u32x3 e = C.e;
   int32_t p = C.p, d = C.d, m = C.m;
   float f = C.f;
@@ -582,7 +591,7 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     }
     s += quad_dpp<0x4E>(s);
     p = (int32_t)s >> 15;
-    d = (j + 1 < kChunk ? x[j + 1 < kChunk ? j + 1 : j] : xn0) - p;
+    d = sample(j + 1) - p;
     m = d >> 31;
     f = (float)d;
     pin(m);
@@ -1135,6 +1144,13 @@ struct ChunkSamples {
       asm volatile("" : "+v"(d[n - 8]), "+v"(d[n - 7]), "+v"(d[n - 6]), "+v"(d[n - 5]), "+v"(d[n - 4]), "+v"(d[n - 3]),
                         "+v"(d[n - 2]), "+v"(d[n - 1]) :: "memory");
   }
+  /* samples 2k and 2k+1 of channel c as one dword (low half first): what the quad encoder keeps
+   * per chunk - its subtract reads the halves directly (SDWA), no per-sample extraction */
+  __device__ __forceinline__ uint32_t pair(int k, uint32_t sel) const
+  {
+    if (CHF == 1) return d[k];
+    return __builtin_amdgcn_perm(d[2 * k + 1], d[2 * k], sel); /* sel = c ? 0x07060302 : 0x05040100 */
+  }
   __device__ __forceinline__ int32_t get(int j, uint32_t c) const
   {
     if (CHF == 1) return __builtin_amdgcn_sbfe((int32_t)d[j >> 1], (j & 1) * 16, 16);
@@ -1263,30 +1279,37 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
     if (full) next.load(xp, ch, c);
     next.touch();
     if constexpr (QUAD) {
-      /* pipeline carried across chunks: chunk k+1's samples are extracted one chunk early */
-      int32_t x[kChunk], xn[kChunk];
+      /* pipeline carried across chunks: chunk k+1's samples are extracted one chunk early.
+       * Without M/S they stay packed two to a dword (kN = 8 registers per chunk); the M/S
+       * transform needs them widened (kN = 16). */
+      constexpr bool PK = !MS;
+      constexpr int kN = PK ? kChunk / 2 : kChunk;
+      const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
+      auto extract = [&](int32_t(&dst)[kN]) {
+#pragma unroll
+        for (int j = 0; j < kN; j++) dst[j] = PK ? (int32_t)next.pair(j, pair_sel) : next.get(j, c);
+      };
+      auto first_sample = [&](const int32_t(&buf)[kN]) -> int32_t { return PK ? (int32_t)(int16_t)buf[0] : buf[0]; };
+      int32_t x[kN], xn[kN];
       EncodeCarry C;
       if (full) {
-#pragma unroll
-        for (int j = 0; j < kChunk; j++) x[j] = next.get(j, c);
+        extract(x);
         if (full > 1) xp += (uint64_t)kChunk * ch;
         next.load(xp, ch, c);
         next.touch();
-#pragma unroll
-        for (int j = 0; j < kChunk; j++) xn[j] = next.get(j, c);
-        encode_prime_quad<BITS>(L, C, x[0], lds);
+        extract(xn);
+        encode_prime_quad<BITS>(L, C, first_sample(x), lds);
       }
       /* x and xn swap roles every chunk (the loop is unrolled by two) so that the samples of
        * chunk k+2 are extracted straight into the buffer chunk k has just freed - rotating the
        * buffers with moves cost 30 instructions per chunk */
-      auto one = [&](uint32_t k, int32_t(&cur)[kChunk], const int32_t(&ahead)[kChunk]) {
+      auto one = [&](uint32_t k, int32_t(&cur)[kN], const int32_t(&ahead)[kN]) {
         if (k + 2 < full) xp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
         next.load(xp, ch, c);
         uint32_t w[2] = {0, 0};
-        encode_chunk16_quad<BITS, EMIT>(L, C, cur, ahead[0], lds, w, last_qd, sq);
+        encode_chunk16_quad<BITS, EMIT, PK>(L, C, cur, ahead[0], lds, w, last_qd, sq);
         next.touch();
-#pragma unroll
-        for (int j = 0; j < kChunk; j++) cur[j] = next.get(j, c);
+        extract(cur);
         if (EMIT && writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD>(body + (uint64_t)k * kOutStride * ch, w, c);
       };
       for (uint32_t k = 0; k < full; k += 2) {
