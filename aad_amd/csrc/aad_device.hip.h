@@ -449,15 +449,21 @@ __device__ __forceinline__ int64_t wrapped_square(int32_t qd) { return (int64_t)
 
 /* EMIT: pack the codes into w[] (the real encode pass); otherwise add the wrapped squares of the
  * dequantised differences to sq (an RMSE pass of the trial search - same recurrence, no output) */
-template <int BITS, bool EMIT, typename S>
+/* PACKED: x holds eight dwords of two int16 samples each instead of sixteen widened values (the
+ * subtract then reads the halves directly, v_sub_u32_sdwa) */
+template <int BITS, bool EMIT, bool PACKED = false, typename S>
 __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq)
 {
+  auto sample = [&](int k) -> int32_t { /* k compile-time after unrolling */
+    if (PACKED) return (k & 1) ? x[k >> 1] >> 16 : (int32_t)(int16_t)x[k >> 1];
+    return x[k];
+  };
   uint32_t sa = slot_addr(L.idxb);
   uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
   float hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
   float hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
   int32_t p = predict(L);
-  int32_t d = x[0] - p;
+  int32_t d = sample(0) - p;
   int32_t m = d >> 31;
   float f = (float)d;
   static_for<0, kChunk>([&](auto jc) {
@@ -496,7 +502,7 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     lms_rest_and_shift(L, qd, y);
     if (j + 1 < kChunk) {
       p = predict(L);
-      d = x[j + 1] - p;
+      d = sample(j + 1) - p;
       m = d >> 31;
       f = (float)d;
       pin(m);
@@ -1317,15 +1323,19 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         if (k + 1 < full) one(k + 1, xn, x);
       }
     } else {
+      /* mono / stereo without M/S: the samples stay packed two to a dword (see encode_chunk16) */
+      constexpr bool PK = CHF != 0 && !MS;
+      constexpr int kN = PK ? kChunk / 2 : kChunk;
+      const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
       for (uint32_t k = 0; k < full; k++) {
-        int32_t x[kChunk];
+        int32_t x[kN];
 #pragma unroll
-        for (int j = 0; j < kChunk; j++) x[j] = next.get(j, c);
+        for (int j = 0; j < kN; j++) x[j] = PK ? (int32_t)next.pair(j, pair_sel) : next.get(j, c);
         /* unconditional prefetch (the last iteration re-reads its own chunk), see the decoder */
         if (k + 1 < full) xp += (uint64_t)kChunk * ch;
         next.load(xp, ch, c);
         uint32_t w[2] = {0, 0};
-        encode_chunk16<BITS, EMIT>(L, x, lds, w, last_qd, sq);
+        encode_chunk16<BITS, EMIT, PK>(L, x, lds, w, last_qd, sq);
         next.touch();
         if (EMIT) {
           if (CHF != 0) {
