@@ -37,6 +37,10 @@ struct AADHipContext {
   bool owns_stream;
   char last_error[256];
   Staging pcm, data, pcm_out;
+  /* scratch of the split decoder (dequantised differences), grow-only and shared by every decode
+   * plan of the context: their runs are ordered by the context's one stream */
+  int32_t *d_residual;
+  uint64_t residual_capacity;
 };
 
 struct AADHipEncodePlan {
@@ -51,8 +55,6 @@ struct AADHipDecodePlan {
   aad::DecodeArgs args;
   aad::StreamDesc *d_streams;
   uint64_t *d_prefix;
-  int32_t *d_residual; /* scratch of the two-kernel decoder, allocated on first use */
-  uint64_t residual_capacity;
 };
 
 struct AADHipReconstructPlan {
@@ -288,6 +290,8 @@ AADApiResult AADHip_ContextCreate(int32_t device_index, void *hip_stream, struct
   ctx->stream = static_cast<hipStream_t>(hip_stream);
   ctx->owns_stream = false;
   ctx->last_error[0] = 0;
+  ctx->d_residual = nullptr;
+  ctx->residual_capacity = 0;
   DeviceGuard guard(ctx);
   if (!guard.ok) {
     delete ctx;
@@ -314,6 +318,7 @@ void AADHip_ContextDestroy(struct AADHipContext *ctx)
       staging_release(ctx->pcm);
       staging_release(ctx->data);
       staging_release(ctx->pcm_out);
+      if (ctx->d_residual) (void)hipFree(ctx->d_residual);
       if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     }
   }
@@ -459,8 +464,6 @@ AADApiResult AADHip_DecodePlanCreate(struct AADHipContext *ctx, const struct AAD
   p->ctx = ctx;
   p->d_streams = nullptr;
   p->d_prefix = nullptr;
-  p->d_residual = nullptr;
-  p->residual_capacity = 0;
   DeviceGuard guard(ctx);
   if (!guard.ok || !upload(ctx, &p->d_streams, reinterpret_cast<const aad::StreamDesc *>(streams), num_streams) ||
       !upload(ctx, &p->d_prefix, prefix.data(), prefix.size())) {
@@ -497,7 +500,6 @@ void AADHip_DecodePlanDestroy(struct AADHipDecodePlan *plan)
     (void)hipStreamSynchronize(plan->ctx->stream);
     (void)hipFree(plan->d_streams);
     (void)hipFree(plan->d_prefix);
-    if (plan->d_residual) (void)hipFree(plan->d_residual);
   }
   delete plan;
 }
@@ -516,17 +518,17 @@ AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *
   uint32_t residual_stride = 0;
   int32_t *residual = nullptr;
   if (want_split_decode(a, &residual_bytes, &residual_stride)) {
-    if (plan->residual_capacity < residual_bytes) { /* first quad run of this plan */
-      if (plan->d_residual) {
+    if (ctx->residual_capacity < residual_bytes) { /* first small-batch decode of this size on the context */
+      if (ctx->d_residual) {
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(plan->d_residual);
-        plan->d_residual = nullptr;
-        plan->residual_capacity = 0;
+        (void)hipFree(ctx->d_residual);
+        ctx->d_residual = nullptr;
+        ctx->residual_capacity = 0;
       }
-      if (!hip_ok(ctx, hipMalloc((void **)&plan->d_residual, residual_bytes), "hipMalloc residual scratch")) return AAD_APIRESULT_NG;
-      plan->residual_capacity = residual_bytes;
+      if (!hip_ok(ctx, hipMalloc((void **)&ctx->d_residual, residual_bytes), "hipMalloc residual scratch")) return AAD_APIRESULT_NG;
+      ctx->residual_capacity = residual_bytes;
     }
-    residual = plan->d_residual;
+    residual = ctx->d_residual;
   }
   switch (a.bits) {
     case 4: launch_decode<4>(a, ctx->stream, residual, residual_stride); break;
