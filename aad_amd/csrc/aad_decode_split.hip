@@ -14,15 +14,21 @@
 
 namespace aad {
 
-template <int BITS>
+template <int BITS, bool LDSRES>
 static void launch_bits(const SplitDecodeArgs &sa, dim3 grid, dim3 block, hipStream_t stream)
 {
   if (sa.d.channels == 1)
-    hipLaunchKernelGGL((decode_split_kernel<BITS, 1, false>), grid, block, 0, stream, sa);
+    hipLaunchKernelGGL((decode_split_kernel<BITS, 1, false, LDSRES>), grid, block, 0, stream, sa);
   else if (sa.d.mid_side)
-    hipLaunchKernelGGL((decode_split_kernel<BITS, 2, true>), grid, block, 0, stream, sa);
+    hipLaunchKernelGGL((decode_split_kernel<BITS, 2, true, LDSRES>), grid, block, 0, stream, sa);
   else
-    hipLaunchKernelGGL((decode_split_kernel<BITS, 2, false>), grid, block, 0, stream, sa);
+    hipLaunchKernelGGL((decode_split_kernel<BITS, 2, false, LDSRES>), grid, block, 0, stream, sa);
+}
+
+bool decode_split_fits_lds(const DecodeArgs &args)
+{
+  const uint32_t coded = args.samples_per_block > 4 ? args.samples_per_block - 4 : 0;
+  return coded <= kLdsResidualMax && args.total_blocks * args.channels <= 4096; /* one workgroup per CU */
 }
 
 bool launch_decode_split(const DecodeArgs &args, int32_t *residual, uint32_t residual_stride, hipStream_t stream)
@@ -35,10 +41,12 @@ bool launch_decode_split(const DecodeArgs &args, int32_t *residual, uint32_t res
   sa.reserved = 0;
   const uint64_t recurrences = args.total_blocks * args.channels;
   const dim3 grid((unsigned)((recurrences + 15) / 16)), block(1024); /* 16 recurrences per workgroup */
+  const bool lds = residual == nullptr;
+  if (lds && !decode_split_fits_lds(args)) return false;
   switch (args.bits) {
-    case 4: launch_bits<4>(sa, grid, block, stream); return true;
-    case 3: launch_bits<3>(sa, grid, block, stream); return true;
-    case 2: launch_bits<2>(sa, grid, block, stream); return true;
+    case 4: lds ? launch_bits<4, true>(sa, grid, block, stream) : launch_bits<4, false>(sa, grid, block, stream); return true;
+    case 3: lds ? launch_bits<3, true>(sa, grid, block, stream) : launch_bits<3, false>(sa, grid, block, stream); return true;
+    case 2: lds ? launch_bits<2, true>(sa, grid, block, stream) : launch_bits<2, false>(sa, grid, block, stream); return true;
     default: return false;
   }
 }

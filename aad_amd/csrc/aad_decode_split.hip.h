@@ -101,7 +101,7 @@ __device__ __forceinline__ ClampAdd then(const ClampAdd &f, const ClampAdd &g)
  */
 template <int BITS>
 __device__ __forceinline__ void residuals_for_recurrence(const SplitDecodeArgs &a, uint64_t rec, uint32_t lane,
-                                                         const uint32_t *s_step, const int32_t *s_delta)
+                                                         const uint32_t *s_step, const int32_t *s_delta, int32_t *out)
 {
   constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes, UNITS = kChunk / US;
   constexpr uint32_t kMagMask = Pack<BITS>::kMagMax, kSign = Pack<BITS>::kSign;
@@ -116,7 +116,6 @@ __device__ __forceinline__ void residuals_for_recurrence(const SplitDecodeArgs &
   int32_t carry = min((int32_t)(load_be16(blk.src + c * kBlockHeaderBytesPerCh) >> 4), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias;
   const uint32_t body = (uint32_t)kBlockHeaderBytesPerCh * ch + c * UB;
   const uint32_t unit_stride = UB * ch;
-  int32_t *out = a.residual + rec * a.residual_stride;
 
   for (uint32_t base = 0; base < coded; base += 64u * kChunk) {
     const uint32_t k0 = base + lane * kChunk;
@@ -263,7 +262,7 @@ __device__ __forceinline__ void predict_chunk16_quad(QuadLane &L, PredictCarry &
  * CHF = 1 or 2 (the quad mapping exists for mono / stereo only).
  */
 template <int CHF, bool MS>
-__device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint64_t thread)
+__device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint64_t thread, const int32_t *res)
 {
   constexpr uint32_t ch = CHF;
   const uint64_t rec = thread >> 2;
@@ -309,7 +308,6 @@ __device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint6
   QuadLane L = to_quad<false>(H, tap);
   const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
   const uint32_t full = coded / kChunk;
-  const int32_t *res = a.residual + (active ? rec : 0) * a.residual_stride;
   int16_t *op = a.d.pcm + blk.pcm_first + (uint64_t)kTaps * ch; /* frame of the chunk's first sample, channel 0 */
 
   PredictCarry C = {0, 0, 0};
@@ -368,13 +366,23 @@ __device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint6
  * Both strands in one launch.  A workgroup is 16 waves and owns 16 recurrences: first every wave
  * runs strand (1) for one of them (lane = 16-sample chunk), then - one barrier later - wave 0
  * alone runs strand (2) for all sixteen on the quad mapping while the other fifteen retire.  The
- * residuals cross over through the scratch buffer (same CU, so through its own L1/L2 path).
+ * residuals cross over through LDS when a block's worth fits (LDSRES) and through the scratch
+ * buffer in device memory otherwise.
  */
-template <int BITS, int CHF, bool MS>
+/* LDS-resident residuals: rows of kLdsResidualRow dwords, enough for blocks of up to
+ * kLdsResidualMax coded samples per channel (every 4-bit geometry up to max_block_size 1024 and
+ * most others); the row length is 20 mod 32 dwords so that the sixteen rows a wave reads at the
+ * same sample offset spread over the banks.  132 KB of the CU's 160 KB: one workgroup per CU,
+ * which is what this path is for (the host uses it up to one workgroup per CU). */
+constexpr uint32_t kLdsResidualMax = 2048;
+constexpr uint32_t kLdsResidualRow = kLdsResidualMax + kChunk + 4;
+
+template <int BITS, int CHF, bool MS, bool LDSRES>
 __global__ void __launch_bounds__(1024) decode_split_kernel(SplitDecodeArgs a)
 {
   __shared__ uint32_t s_step[AAD_STEP_TABLE_LEN];
   __shared__ int32_t s_delta[8];
+  __shared__ __attribute__((aligned(16))) int32_t s_res[LDSRES ? 16 * kLdsResidualRow : 4];
   for (uint32_t i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) s_step[i] = c_step_table[i];
   if (threadIdx.x < 8) {
     const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
@@ -382,12 +390,21 @@ __global__ void __launch_bounds__(1024) decode_split_kernel(SplitDecodeArgs a)
   }
   __syncthreads();
   {
-    const uint64_t rec = (uint64_t)blockIdx.x * 16u + (threadIdx.x >> 6);
-    if (rec < a.d.total_blocks * CHF) residuals_for_recurrence<BITS>(a, rec, threadIdx.x & 63u, s_step, s_delta);
+    const uint32_t w = threadIdx.x >> 6;
+    const uint64_t rec = (uint64_t)blockIdx.x * 16u + w;
+    if (rec < a.d.total_blocks * CHF)
+      residuals_for_recurrence<BITS>(a, rec, threadIdx.x & 63u, s_step, s_delta,
+                                     LDSRES ? s_res + w * kLdsResidualRow : a.residual + rec * a.residual_stride);
   }
-  __syncthreads(); /* the residuals are in memory before wave 0 reads them (workgroup-scope release/acquire) */
+  /* the residuals are in LDS / in memory before wave 0 reads them (workgroup-scope release/acquire) */
+  __syncthreads();
   if (threadIdx.x >= 64) return;
-  predict_for_quad<CHF, MS>(a, (uint64_t)blockIdx.x * 64u + threadIdx.x);
+  const uint64_t thread = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+  const uint64_t rec = thread >> 2;
+  const bool active = rec < a.d.total_blocks * CHF;
+  predict_for_quad<CHF, MS>(a, thread,
+                            LDSRES ? s_res + (threadIdx.x >> 2) * kLdsResidualRow
+                                   : a.residual + (active ? rec : 0) * a.residual_stride);
 }
 
 } /* namespace aad */

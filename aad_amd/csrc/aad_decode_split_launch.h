@@ -11,8 +11,11 @@
 
 namespace aad {
 struct DecodeArgs;
-/* decode_split_kernel<bits, channels (1 or 2), mid_side> over ceil(recurrences / 16) workgroups of
- * 1024 threads; false when (bits, channels) has no instantiation */
+/* true when the batch is small enough, and its blocks short enough, for the residuals to stay in LDS */
+bool decode_split_fits_lds(const DecodeArgs &args);
+/* decode_split_kernel<bits, channels (1 or 2), mid_side, residuals in LDS> over ceil(recurrences / 16)
+ * workgroups of 1024 threads.  residual == nullptr selects the LDS form (decode_split_fits_lds must
+ * hold), otherwise the rows go through that device buffer.  false when nothing was launched. */
 bool launch_decode_split(const DecodeArgs &args, int32_t *residual, uint32_t residual_stride, hipStream_t stream);
 } /* namespace aad */
 

@@ -517,8 +517,10 @@ AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *
   uint64_t residual_bytes = 0;
   uint32_t residual_stride = 0;
   int32_t *residual = nullptr;
-  if (want_split_decode(a, &residual_bytes, &residual_stride)) {
-    if (ctx->residual_capacity < residual_bytes) { /* first small-batch decode of this size on the context */
+  bool split = want_split_decode(a, &residual_bytes, &residual_stride);
+  const bool split_in_lds = split && aad::decode_split_fits_lds(a);
+  if (split && !split_in_lds) {
+    if (ctx->residual_capacity < residual_bytes) { /* first such decode of this size on the context */
       if (ctx->d_residual) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(ctx->d_residual);
@@ -529,6 +531,10 @@ AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *
       ctx->residual_capacity = residual_bytes;
     }
     residual = ctx->d_residual;
+  }
+  if (split_in_lds) {
+    if (!aad::launch_decode_split(a, nullptr, 0, ctx->stream)) return AAD_APIRESULT_INVALID_FORMAT;
+    return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
   }
   switch (a.bits) {
     case 4: launch_decode<4>(a, ctx->stream, residual, residual_stride); break;
