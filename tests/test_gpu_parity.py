@@ -374,3 +374,34 @@ def test_extreme_block_sizes(engine, mapping):
         dec = engine.decode_host(images)
         for s in range(2):
             assert np.array_equal(dec[s], ob.decode(images[s])[0]), (ch, bits, mbs)
+
+
+@pytest.mark.parametrize("streams,bits,ch", [(3000, 4, 2), (7000, 4, 1), (9000, 3, 2), (12000, 2, 2)])
+def test_decode_mapping_ranges_auto(engine, streams, bits, ch):
+    """The host's own choice of decode mapping across its thresholds (no AAD_HIP_MAPPING): split
+    decoder with the residuals in a device scratch buffer (more than one workgroup per CU),
+    fused quad kernel, dense kernel - one-block streams, sampled against the oracle, and the whole
+    batch through the round trip decode(encode(x)) == oracle decode."""
+    import torch
+    os.environ.pop("AAD_HIP_MAPPING", None)
+    spb = {4: 1984, 3: 2632, 2: 3960}[bits] // ch
+    base = synth_pcm(500, spb, ch, seed=2024 + streams)
+    pcm = np.concatenate([base] * (-(-streams // 500)))[:streams]
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    param = make_parameter(ch, bits, 1024, 48000, False, 0)
+    d_img, size = engine.encode_uniform(d_pcm, param)
+    d_dec, _ = engine.decode_uniform(d_img, size)
+    torch.cuda.synchronize()
+    img, dec = d_img.cpu().numpy(), d_dec.cpu().numpy()
+    want = {}
+    for s in list(range(0, 500, 61)) + [499]:
+        w_img = ob.encode(base[s], bits, 1024)
+        want[s] = (w_img, ob.decode(w_img)[0])
+    for s in range(streams):
+        if s % 500 in want:
+            w_img, w_dec = want[s % 500]
+            assert bytes(img[s, :size]) == w_img, s
+            assert np.array_equal(dec[s], w_dec), s
+    # every copy of a base stream decodes identically
+    assert np.array_equal(dec[:500], dec[500:1000])
+    assert np.array_equal(dec[streams - 500:], dec[(streams - 500) % 500:][:500]) if streams % 500 == 0 else True
