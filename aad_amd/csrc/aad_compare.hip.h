@@ -21,7 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "aad_device.hip.h"
+#include "aad_decode.hip.h" /* StreamDesc, find_stream */
 
 namespace aad {
 

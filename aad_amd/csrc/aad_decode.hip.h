@@ -1,0 +1,485 @@
+/*
+ * aad_decode.hip.h - the decoder side of the device code: single step, the hand-pipelined
+ * 16-sample chunk bodies (dense and quad mapping), code fetch, PCM stores and
+ * decode_blocks_kernel, the one-lane-does-both-strands decoder (reference
+ * src/aad_decoder.c:269-475).  The split decoder for small batches is aad_decode_split.hip.h;
+ * shared pieces (tables, lane state, LMS, prediction, shuffles) are in aad_device.hip.h.
+ */
+#ifndef AAD_DECODE_HIP_H
+#define AAD_DECODE_HIP_H
+
+#include "aad_device.hip.h"
+
+namespace aad {
+
+/* one decoder step - reference src/aad_decoder.c:269-318; `code` in the low BITS bits.  Plain
+ * form for tails; the bulk goes through decode_chunk16. */
+template <int BITS, typename S>
+__device__ __forceinline__ int32_t decode_step(S &L, uint32_t code, const char *lds)
+{
+  const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
+  const u32x3 t = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + ((code & ((1u << BITS) - 1u)) << 4));
+  const int32_t qd = mad_i24((int32_t)step, (int32_t)t.x, (int32_t)t.y) >> (BITS - 1);
+  const int32_t y = clip16(qd + predict(L));
+  L.idxb = clamp_idx(L.idxb + (int32_t)t.z);
+  lms_and_shift(L, qd, y);
+  return y;
+}
+
+/*
+ * Sixteen decoder steps, software-pipelined by hand.  Codes are known a chunk ahead, so the
+ * per-code record of sample j+2 is fetched during sample j; the only lookup on the recurrence
+ * is the step size of the next sample, started as soon as the new index is known and hidden
+ * behind this sample's reconstruction, LMS update and the next prediction (~22 instructions).
+ *   A  step index of the next sample; start its step lookup and the record lookup of sample j+2
+ *   B  dequantise (mad + shift), reconstruct, LMS, history shift, predict the next sample
+ */
+template <int BITS, typename S, typename Finish>
+__device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const char *lds, int32_t *y, Finish finish)
+{
+  constexpr int cpw = Pack<BITS>::kCodesPerWord;
+  auto code_addr = [&](int j) -> uint32_t { /* (code << 4) for sample j, j compile-time after unrolling */
+    const int pos = Pack<BITS>::pos(j % cpw);
+    const uint32_t word = w[j / cpw];
+    return (pos >= 4 ? word >> (pos >= 4 ? pos - 4 : 0) : word << (4 - pos)) & (((1u << BITS) - 1u) << 4);
+  };
+  uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
+  /* per-code records two samples ahead: they depend on nothing but the code bits */
+  u32x3 t0 = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(0));
+  u32x3 t1 = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(1));
+  int32_t p = predict(L);
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    /* A */
+    const uint32_t step_j = step;
+    const u32x3 t_j = t0;
+    t0 = t1;
+    L.idxb = clamp_idx(L.idxb + (int32_t)t_j.z);
+    if (j + 1 < kChunk) step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
+    if (j + 2 < kChunk) t1 = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(j + 2 < kChunk ? j + 2 : j));
+    __builtin_amdgcn_sched_barrier(0);
+    /* B */
+    const int32_t qd = mad_i24((int32_t)step_j, (int32_t)t_j.x, (int32_t)t_j.y) >> (BITS - 1);
+    const int32_t yy = clip16(qd + p);
+    lms_and_shift(L, qd, yy);
+    if (j + 1 < kChunk) {
+      p = predict(L);
+      pin(p);
+    } else {
+      pin_weights(L);
+    }
+    y[j] = finish(yy);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+/*
+ * Sixteen decoder steps for the quad mapping.  The prediction's two DPP butterfly adds each need
+ * wait states after the instruction that wrote their operand (the compiler pads with s_nop, ~4-8
+ * cycles apiece for a lone wave).  The decoder's step-index chain depends only on the codes, so
+ * it is run one sample further ahead than in decode_chunk16 and its instructions are placed
+ * exactly in those gaps: index update + record lookup after the product, slot address + step
+ * lookup after the first butterfly add.  In flight per lane: the step sizes of samples j+1 and
+ * j+2 and the per-code records of samples j+1 .. j+3.
+ *
+ * The pipeline is carried from chunk to chunk (DecodeCarry) instead of being re-primed every 16
+ * samples - a re-prime costs two exposed LDS round trips and a DPP reduction, ~170 cycles.  For
+ * that the last three samples of a chunk look their records up in the NEXT chunk's code words
+ * (wn), which the kernel unpacks one chunk early.
+ */
+struct DecodeCarry {
+  uint32_t step0, step1; /* step sizes of samples j, j+1 */
+  u32x3 t0, t1, t2;      /* per-code records of samples j, j+1, j+2 */
+  int32_t p;             /* prediction for sample j */
+  int32_t idx_next;      /* step index (biased) of the first sample after the chunk just finished */
+};
+
+template <int BITS>
+__device__ __forceinline__ uint32_t chunk_code_addr(const uint32_t *w, const uint32_t *wn, int j)
+{
+  constexpr int cpw = Pack<BITS>::kCodesPerWord;
+  const uint32_t word = j < kChunk ? w[j / cpw] : wn[(j - kChunk) / cpw];
+  const int pos = Pack<BITS>::pos((j % kChunk) % cpw);
+  return (pos >= 4 ? word >> (pos >= 4 ? pos - 4 : 0) : word << (4 - pos)) & (((1u << BITS) - 1u) << 4);
+}
+
+template <int BITS>
+__device__ __forceinline__ void decode_prime_quad(QuadLane &L, DecodeCarry &C, const uint32_t *w, const char *lds)
+{
+  auto record = [&](int j) { return *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + chunk_code_addr<BITS>(w, w, j)); };
+  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsWideOff + wide_addr(idxb)); };
+  C.step0 = step_at(L.idxb);
+  C.t0 = record(0);
+  C.t1 = record(1);
+  C.t2 = record(2);
+  L.idxb = clamp_idx(L.idxb + (int32_t)C.t0.z); /* from here on L.idxb runs one sample ahead */
+  C.step1 = step_at(L.idxb);
+  C.p = predict(L);
+  C.idx_next = L.idxb;
+}
+
+template <int BITS, typename Finish>
+__device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, DecodeCarry &C, const uint32_t *w, const uint32_t *wn,
+                                                    const char *lds, int32_t *y, Finish finish)
+{
+  auto record = [&](int j) { return *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + chunk_code_addr<BITS>(w, wn, j)); };
+  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsWideOff + wide_addr(idxb)); };
+  uint32_t step0 = C.step0, step1 = C.step1;
+  u32x3 t0 = C.t0, t1 = C.t1, t2 = C.t2;
+  int32_t p = C.p;
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int32_t qd = mad_i24((int32_t)step0, (int32_t)t0.x, (int32_t)t0.y) >> (BITS - 1);
+    const int32_t yy = clip16(qd + p);
+    lms_and_shift<true>(L, qd, yy);
+    y[j] = finish(yy);
+    uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
+    pin(s);
+    /* gap 1: index of sample j+2 and the record lookup of sample j+3.  The record is started
+     * BEFORE the step lookup below: LDS results return in order, so the wait for a step size at
+     * the top of a sample also covers the record whose delta is needed in the middle of the one
+     * before - one s_waitcnt per sample, not two. */
+    int32_t idx2 = clamp_idx(L.idxb + (int32_t)t1.z);
+    const u32x3 t3 = record(j + 3);
+    pin(idx2);
+    s += quad_dpp<0xB1>(s);
+    pin(s);
+    /* gap 2: start the step lookup that hangs on the new index */
+    const uint32_t step2 = step_at(idx2);
+    s += quad_dpp<0x4E>(s);
+    p = (int32_t)s >> 15;
+    pin(p);
+    if (j == kChunk - 2) C.idx_next = idx2; /* index of sample 16: what a non-pipelined continuation needs */
+    step0 = step1;
+    step1 = step2;
+    t0 = t1;
+    t1 = t2;
+    t2 = t3;
+    L.idxb = idx2;
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  C.step0 = step0;
+  C.step1 = step1;
+  C.t0 = t0;
+  C.t1 = t1;
+  C.t2 = t2;
+  C.p = p;
+}
+
+/* ================================================================================ decode == */
+
+struct DecodeArgs {
+  const StreamDesc *streams;
+  const uint64_t *block_prefix; /* [num_streams + 1] exclusive prefix sum of blocks per stream */
+  const uint8_t *data;
+  int16_t *pcm;
+  uint64_t total_blocks;
+  uint32_t num_streams;
+  uint32_t channels;
+  uint32_t block_size;
+  uint32_t samples_per_block;
+  uint32_t header_bytes; /* 31 (file image) or 0 (bare block) */
+  uint32_t mid_side;
+  uint32_t bits;
+  UniformLayout uni;
+};
+
+/* last stream whose first block index is <= g */
+__device__ __forceinline__ uint32_t find_stream(const uint64_t *prefix, uint32_t num_streams, uint64_t g)
+{
+  uint32_t lo = 0, hi = num_streams;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (prefix[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint32_t load_be16(const uint8_t *p) { return ((uint32_t)p[0] << 8) | p[1]; }
+
+/* Code words of one 16-sample chunk of channel c.  CHF = 1 or 2 channels (fast paths: one wide
+ * unaligned load, per-lane v_perm selectors pull the lane's own bytes out of the L/R interleave
+ * and turn them big-endian).  `p` points at the first byte of the chunk's first unit of channel 0. */
+template <int BITS, int CHF>
+struct ChunkCodes {
+  uint32_t r[4]; /* raw dwords as loaded */
+  /* bytes the wide load touches, measured from p */
+  static constexpr int kLoadBytes = CHF == 1 ? (BITS == 2 ? 4 : 8) : (BITS == 4 ? 16 : (BITS == 3 ? 12 : 8));
+  static constexpr int kRaw = kLoadBytes / 4;
+  __device__ __forceinline__ void load(const uint8_t *p)
+  {
+    if (kRaw == 1) {
+      r[0] = reinterpret_cast<const U32 *>(p)->v;
+    } else if (kRaw == 2) {
+      const u32x2 d = reinterpret_cast<const U32x2 *>(p)->v;
+      r[0] = d.x; r[1] = d.y;
+    } else if (kRaw == 3) {
+      const u32x3 d = reinterpret_cast<const U32x3 *>(p)->v;
+      r[0] = d.x; r[1] = d.y; r[2] = d.z;
+    } else {
+      const u32x4 d = reinterpret_cast<const U32x4 *>(p)->v;
+      r[0] = d.x; r[1] = d.y; r[2] = d.z; r[3] = d.w;
+    }
+  }
+  /* Claim the loaded registers without emitting an instruction: the compiler has to place the
+   * s_waitcnt for the prefetch HERE (a whole chunk of arithmetic after it was issued) instead of
+   * at the top of the next iteration behind a burst of fresh stores - gfx950 has one vmcnt for
+   * loads and stores, so a wait placed after the stores would also wait for every one of them. */
+  __device__ __forceinline__ void touch()
+  {
+    if (kRaw == 1) asm volatile("" : "+v"(r[0]) :: "memory");
+    if (kRaw == 2) asm volatile("" : "+v"(r[0]), "+v"(r[1]) :: "memory");
+    if (kRaw == 3) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) :: "memory");
+    if (kRaw == 4) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+  }
+  /* big-endian code words of channel c */
+  __device__ __forceinline__ void unpack(uint32_t c, uint32_t *w) const
+  {
+    if (CHF == 1) {
+      if (BITS == 2) {
+        w[0] = perm(0, r[0], 0x00010203);
+      } else if (BITS == 4) {
+        w[0] = perm(0, r[0], 0x00010203);
+        w[1] = perm(0, r[1], 0x00010203);
+      } else { /* two 3-byte units */
+        w[0] = perm(r[1], r[0], 0x0c000102);
+        w[1] = perm(r[1], r[0], 0x0c030405);
+      }
+    } else {
+      if (BITS == 4) { /* L R L R ...: own bytes c, c+2 of every dword */
+        const uint32_t sel = 0x00020406u + c * 0x01010101u;
+        w[0] = perm(r[1], r[0], sel);
+        w[1] = perm(r[3], r[2], sel);
+      } else if (BITS == 2) {
+        w[0] = perm(r[1], r[0], 0x00020406u + c * 0x01010101u);
+      } else { /* L3 R3 L3 R3 */
+        w[0] = perm(r[1], r[0], c ? 0x0c030405u : 0x0c000102u);
+        w[1] = perm(r[2], r[1], c ? 0x0c050607u : 0x0c020304u);
+      }
+    }
+  }
+};
+
+/* Write 16 decoded samples of channel c (y[], int16 range) as interleaved PCM.  Mono: two 16-byte
+ * stores.  Stereo: the two lanes of a pair trade half of their packed samples through DPP and
+ * each writes 2 x 16 contiguous bytes of L/R frames.  A vector-memory instruction costs a lone
+ * wave ~17 cycles to issue whatever its width, so few wide stores beat one short per sample. */
+template <int CHF, bool QUAD>
+__device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *y, uint32_t c, uint32_t ch)
+{
+  if (CHF == 1) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      u32x4 v;
+      v.x = perm((uint32_t)y[8 * h + 1], (uint32_t)y[8 * h + 0], 0x05040100);
+      v.y = perm((uint32_t)y[8 * h + 3], (uint32_t)y[8 * h + 2], 0x05040100);
+      v.z = perm((uint32_t)y[8 * h + 5], (uint32_t)y[8 * h + 4], 0x05040100);
+      v.w = perm((uint32_t)y[8 * h + 7], (uint32_t)y[8 * h + 6], 0x05040100);
+      reinterpret_cast<U32x4 *>(frame0 + 8 * h)->v = v;
+    }
+  } else if (CHF == 2) {
+    /* per 8 samples: lane 0 writes frames 0-3 (own samples 0-3 + partner's), lane 1 frames 4-7 */
+    const uint32_t sel_lo = c ? 0x05040100u : 0x01000504u, sel_hi = c ? 0x07060302u : 0x03020706u;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint32_t p0 = perm((uint32_t)y[8 * h + 1], (uint32_t)y[8 * h + 0], 0x05040100);
+      const uint32_t p1 = perm((uint32_t)y[8 * h + 3], (uint32_t)y[8 * h + 2], 0x05040100);
+      const uint32_t p2 = perm((uint32_t)y[8 * h + 5], (uint32_t)y[8 * h + 4], 0x05040100);
+      const uint32_t p3 = perm((uint32_t)y[8 * h + 7], (uint32_t)y[8 * h + 6], 0x05040100);
+      const uint32_t ra = pair_swap<QUAD>(c ? p0 : p2, c), rb = pair_swap<QUAD>(c ? p1 : p3, c);
+      const uint32_t ka = c ? p2 : p0, kb = c ? p3 : p1;
+      u32x4 v;
+      v.x = perm(ka, ra, sel_lo);
+      v.y = perm(ka, ra, sel_hi);
+      v.z = perm(kb, rb, sel_lo);
+      v.w = perm(kb, rb, sel_hi);
+      reinterpret_cast<U32x4 *>(frame0 + 16 * h + 8 * c)->v = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kChunk; j++) frame0[(uint32_t)j * ch + c] = (int16_t)y[j];
+  }
+}
+
+/*
+ * Block-parallel decode (reference src/aad_decoder.c:321-475, looped by :514-534).
+ * CHF: 1 / 2 = specialised channel counts with wide chunk loads, 0 = any channel count (byte loads).
+ */
+template <int BITS, int CHF, bool MS, bool QUAD>
+__global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
+{
+  static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
+  __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+  stage_tables<BITS, QUAD>(lds);
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+
+  const uint32_t ch = CHF ? CHF : a.channels;
+  const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t lane = QUAD ? thread >> 2 : thread; /* index of the (block, channel) recurrence */
+  const uint32_t tap = QUAD ? threadIdx.x & 3u : 0u;
+  const bool writer = tap == 0;                      /* quad: all four lanes hold the samples, one stores them */
+  const bool active = lane < a.total_blocks * ch;
+  const uint64_t g = active ? lane / ch : 0;
+  const uint32_t c = active ? (uint32_t)(lane % ch) : 0;
+
+  uint32_t s;
+  StreamDesc sd;
+  uint64_t b;
+  if (a.uni.enabled) { /* wave-uniform branch */
+    s = (uint32_t)g / a.uni.blocks_per_stream; /* the host only enables this below 2^32 blocks */
+    b = (uint32_t)g - s * a.uni.blocks_per_stream;
+    sd = uniform_stream(a.uni, s);
+  } else {
+    s = find_stream(a.block_prefix, a.num_streams, g);
+    sd = a.streams[s];
+    b = g - a.block_prefix[s];
+  }
+  const uint64_t first = b * a.samples_per_block;
+  uint32_t n = 0;
+  if (active && first < sd.num_samples) {
+    const uint64_t left = sd.num_samples - first;
+    n = left < a.samples_per_block ? (uint32_t)left : a.samples_per_block;
+  }
+  /* bytes of this stream still present from the start of this block */
+  const uint64_t block_off = a.header_bytes + b * a.block_size;
+  const uint64_t avail64 = sd.data_size > block_off ? sd.data_size - block_off : 0;
+  const uint32_t avail = avail64 > 0x7FFFFFFFu ? 0x7FFFFFFFu : (uint32_t)avail64;
+  const uint8_t *src = a.data + sd.data_offset + block_off;
+  int16_t *dst = a.pcm + sd.pcm_offset + first * ch + c;
+  if (avail < (uint32_t)kBlockHeaderBytesPerCh * ch) n = 0; /* DecodeBlock: INSUFFICIENT_DATA (reported by the host) */
+
+  Lane H = {0, 0, 0, 0, 0, 0, 0, 0, kIdxBias};
+  if (n) { /* block header - reference src/aad_decoder.c:364-380 */
+    const uint8_t *hp = src + c * kBlockHeaderBytesPerCh;
+    const uint32_t v = load_be16(hp);
+    H.idxb = min((int32_t)(v >> 4), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias;
+    const uint32_t shift = v & 0xFu;
+    H.w0 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 2) << shift);
+    H.h0 = (int16_t)load_be16(hp + 4);
+    H.w1 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 6) << shift);
+    H.h1 = (int16_t)load_be16(hp + 8);
+    H.w2 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 10) << shift);
+    H.h2 = (int16_t)load_be16(hp + 12);
+    H.w3 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 14) << shift);
+    H.h3 = (int16_t)load_be16(hp + 16);
+  }
+
+  /* inverse mid/side needs the partner channel's sample: the lanes of channels 0/1 of a block
+   * are neighbours (4 apart in the quad mapping) and run the same trip counts, so the swap
+   * always meets an active lane */
+  auto finish = [&](int32_t y) -> int32_t {
+    if (MS) {
+      const int32_t other = (int32_t)pair_swap<QUAD>((uint32_t)y, c);
+      return c == 0 ? clip16(y + other) : clip16(other - y);
+    }
+    return y;
+  };
+
+  /* the first four samples are stored verbatim in the header - reference :386-391 */
+  {
+    const int32_t y0 = finish(H.h3), y1 = finish(H.h2), y2 = finish(H.h1), y3 = finish(H.h0);
+    if (writer) {
+      if (n > 0) dst[0] = (int16_t)y0;
+      if (n > 1) dst[ch] = (int16_t)y1;
+      if (n > 2) dst[2 * ch] = (int16_t)y2;
+      if (n > 3) dst[3 * ch] = (int16_t)y3;
+    }
+  }
+  using S = std::conditional_t<QUAD, QuadLane, Lane>;
+  S L;
+  if constexpr (QUAD) L = to_quad<false>(H, tap); else L = H;
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+
+  constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
+  const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
+  uint32_t done = 0; /* coded samples finished */
+
+  if (CHF != 0) {
+    /* full 16-sample chunks whose wide load stays inside the stream's bytes */
+    using CC = ChunkCodes<BITS, (CHF ? CHF : 1)>;
+    constexpr uint32_t kStride = Pack<BITS>::kChunkBytes * (CHF ? CHF : 1);
+    const uint32_t body = (uint32_t)kBlockHeaderBytesPerCh * ch;
+    uint32_t full = coded / kChunk;
+    if (avail < body + CC::kLoadBytes) {
+      full = 0;
+    } else {
+      const uint32_t fit = (avail - body - CC::kLoadBytes) / kStride + 1;
+      full = full < fit ? full : fit;
+    }
+    const uint8_t *cp = src + body;
+    int16_t *op = a.pcm + sd.pcm_offset + (first + kTaps) * ch; /* frame of this chunk's first sample, channel 0 */
+    CC next;
+    next.r[0] = next.r[1] = next.r[2] = next.r[3] = 0;
+    if (full) next.load(cp);
+    next.touch();
+    if constexpr (QUAD) {
+      /* pipeline carried across chunks: the code words of chunk k+1 are unpacked one chunk early */
+      uint32_t w[2] = {0, 0}, wn[2] = {0, 0};
+      DecodeCarry C;
+      if (full) {
+        next.unpack(c, w);
+        if (full > 1) cp += kStride;
+        next.load(cp);
+        next.touch();
+        next.unpack(c, wn);
+        decode_prime_quad<BITS>(L, C, w, lds);
+      }
+      for (uint32_t k = 0; k < full; k++) {
+        /* prefetch chunk k+2 (clamped to the last full chunk), consumed after this chunk's arithmetic */
+        if (k + 2 < full) cp += kStride;
+        next.load(cp);
+        int32_t y[kChunk];
+        decode_chunk16_quad<BITS>(L, C, w, wn, lds, y, finish);
+        next.touch();
+        w[0] = wn[0];
+        w[1] = wn[1];
+        next.unpack(c, wn);
+        if (writer) store_chunk_pcm<CHF, QUAD>(op, y, c, ch);
+        op += (uint64_t)kChunk * ch;
+      }
+      if (full) L.idxb = C.idx_next; /* drop the run-ahead: the tail below is not pipelined */
+    } else {
+      for (uint32_t k = 0; k < full; k++) {
+        uint32_t w[2] = {0, 0};
+        next.unpack(c, w);
+        /* prefetch the next chunk (the last iteration re-reads its own: an unconditional load lands
+         * straight in `next`'s registers, a conditional one would be copied - and waited for - at once);
+         * it is consumed (touch) only after this chunk's arithmetic */
+        if (k + 1 < full) cp += kStride;
+        next.load(cp);
+        int32_t y[kChunk];
+        decode_chunk16<BITS>(L, w, lds, y, finish);
+        next.touch();
+        if (writer) store_chunk_pcm<CHF, QUAD>(op, y, c, ch);
+        op += (uint64_t)kChunk * ch;
+      }
+    }
+    done = full * kChunk;
+  }
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+
+  /* remaining units (all of them when CHF == 0): byte loads, bytes past the stream read as zero */
+  {
+    const uint32_t unit_stride = UB * ch;
+    const uint32_t base = (uint32_t)kBlockHeaderBytesPerCh * ch + c * UB;
+    for (uint32_t i = done; i < coded; i += US) {
+      const uint32_t o = base + (i / US) * unit_stride;
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < UB; k++) acc = (acc << 8) | (o + k < avail ? (uint32_t)src[o + k] : 0u);
+      acc <<= 32 - 8 * UB; /* codes to the top of the word */
+#pragma unroll
+      for (int k = 0; k < US; k++) {
+        const int32_t y = finish(decode_step<BITS>(L, acc >> (32 - BITS), lds));
+        acc <<= BITS;
+        if (writer && i + k < coded) dst[(uint64_t)(kTaps + i + k) * ch] = (int16_t)y;
+      }
+    }
+  }
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+}
+
+} /* namespace aad */
+
+#endif /* AAD_DECODE_HIP_H */

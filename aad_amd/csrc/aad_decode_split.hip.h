@@ -29,7 +29,7 @@
 #ifndef AAD_DECODE_SPLIT_HIP_H
 #define AAD_DECODE_SPLIT_HIP_H
 
-#include "aad_device.hip.h"
+#include "aad_decode.hip.h"
 
 namespace aad {
 

@@ -1,0 +1,714 @@
+/*
+ * aad_encode.hip.h - the encoder side of the device code: single step, the hand-pipelined
+ * 16-sample chunk bodies (dense and quad mapping), sample fetch, block framing and code stores,
+ * the trial search, and encode_streams_kernel (reference src/aad_encoder.c:343-727, 814-891).
+ * Shared pieces (tables, lane state, LMS, prediction, shuffles) are in aad_device.hip.h.
+ */
+#ifndef AAD_ENCODE_HIP_H
+#define AAD_ENCODE_HIP_H
+
+#include "aad_device.hip.h"
+
+namespace aad {
+
+/* Q4 step-index delta of a magnitude code as arithmetic (the constants of reference
+ * src/aad_tables.c:8-45): 4-bit {-18,-17,-14,16,32,64,128,256}, 3-bit {-16,-15,32,128},
+ * 2-bit {-14,40}.  Five instructions instead of an LDS lookup: used where that lookup would sit
+ * on the recurrence's critical path and there are instruction slots to spare (quad encoder). */
+template <int BITS>
+__device__ __forceinline__ int32_t index_delta_arith(uint32_t mag)
+{
+  if (BITS == 4) {
+    /* 2 << mag, minus {20, 21, 22, 0, 0, 0, 0, 0}[mag] picked by one v_perm_b32 byte lookup
+     * (selector bytes 1-3 = 0x0c give zero): no compare/select pair, no SGPR hazard */
+    const uint32_t corr = __builtin_amdgcn_perm(0u, 0x00161514u, mag | 0x0c0c0c00u);
+    return (int32_t)(2u << mag) - (int32_t)corr;
+  } else if (BITS == 3) {
+    return mag < 2 ? (int32_t)mag - 16 : (int32_t)(2u << (2u * mag));
+  } else {
+    return mag ? 40 : -14;
+  }
+}
+
+/* one encoder step - reference src/aad_encoder.c:343-410.  Returns the code; qd is the
+ * dequantised difference (the reference's quantize_error).  Plain form, used for tails and the
+ * trial search; the bulk goes through encode_chunk16.  S = Lane or QuadLane. */
+template <int BITS, typename S>
+__device__ __forceinline__ uint32_t encode_step(S &L, int32_t x, const char *lds, int32_t &qd)
+{
+  const uint32_t sa = slot_addr(L.idxb);
+  const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
+  const float hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
+  const float hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+  const int32_t p = predict(L);
+  const int32_t d = x - p;
+  const int32_t m = d >> 31; /* 0 or -1 */
+  /* min((|d| << (BITS-2)) / step, magmax) == min(trunc(fma(|d|, 2^(BITS-1)*hr, hr)), magmax), hr = fl32(0.5/step) */
+  const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf((float)d), hs, hr), Pack<BITS>::kMagMax);
+  const uint32_t m21 = (mag << 1) | 1u;
+  const int32_t q = (int32_t)(__umul24(step, m21) >> (BITS - 1));
+  qd = (q ^ m) - m;
+  /* m21 = 2*mag + 1 addresses the int16 delta table: byte offset 2*mag = m21 - 1 */
+  const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDeltaOff - 1) + m21);
+  L.idxb = clamp_idx(L.idxb + delta);
+  lms_and_shift(L, qd, clip16(qd + p));
+  return mag | ((uint32_t)m & Pack<BITS>::kSign);
+}
+
+/*
+ * Sixteen encoder steps, software-pipelined by hand.  The encoder's recurrence runs through two
+ * dependent LDS lookups per sample (code -> index delta -> step record of the NEXT sample), ~55
+ * cycles each for a lone wave.  The compiler's schedule waits for both right after issuing
+ * them; here every sample is cut into four regions separated by scheduling barriers so that
+ * each lookup has ~15 independent instructions (~60 cycles) issued behind it:
+ *   A  quantise with the step record fetched during the previous sample; start the delta lookup
+ *   B  dequantise, reconstruct, LMS taps 0-1, pack the code            (hides the delta lookup)
+ *   C  new step index; start the lookup of the next sample's step record
+ *   D  LMS taps 2-3, history shift, predict + difference of the NEXT sample (hides the record lookup)
+ * Same arithmetic as encode_step, instruction for instruction.
+ */
+/* squared dequantised difference as the reference accumulates it (src/aad_encoder.c:461): the
+ * product wraps in int32 before it is widened (SURVEY.md finding 5) */
+__device__ __forceinline__ int64_t wrapped_square(int32_t qd) { return (int64_t)(int32_t)((uint32_t)qd * (uint32_t)qd); }
+
+/* EMIT: pack the codes into w[] (the real encode pass); otherwise add the wrapped squares of the
+ * dequantised differences to sq (an RMSE pass of the trial search - same recurrence, no output) */
+/* PACKED: x holds eight dwords of two int16 samples each instead of sixteen widened values (the
+ * subtract then reads the halves directly, v_sub_u32_sdwa) */
+template <int BITS, bool EMIT, bool PACKED = false, typename S>
+__device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq)
+{
+  auto sample = [&](int k) -> int32_t { /* k compile-time after unrolling */
+    if (PACKED) return (k & 1) ? x[k >> 1] >> 16 : (int32_t)(int16_t)x[k >> 1];
+    return x[k];
+  };
+  uint32_t sa = slot_addr(L.idxb);
+  uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
+  float hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
+  float hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+  int32_t p = predict(L);
+  int32_t d = sample(0) - p;
+  int32_t m = d >> 31;
+  float f = (float)d;
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    /* A */
+    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), hs, hr), Pack<BITS>::kMagMax);
+    const uint32_t m21 = (mag << 1) | 1u;
+    const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDeltaOff - 1) + m21);
+    __builtin_amdgcn_sched_barrier(0);
+    /* B */
+    const int32_t q = (int32_t)(__umul24(step, m21) >> (BITS - 1));
+    const int32_t qd = (q ^ m) - m;
+    const int32_t y = clip16(qd + p);
+    lms_first(L, qd);
+    if (EMIT) {
+      uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
+      uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
+      pin(code);
+      acc = (acc << BITS) | code;                               /* v_lshl_or_b32 */
+      pin(acc);
+    } else {
+      sq += wrapped_square(qd);
+    }
+    pin_weights(L);
+    __builtin_amdgcn_sched_barrier(0);
+    /* C */
+    L.idxb = clamp_idx(L.idxb + delta);
+    if (j + 1 < kChunk) {
+      sa = slot_addr(L.idxb);
+      step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
+      hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
+      hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    /* D */
+    lms_rest_and_shift(L, qd, y);
+    if (j + 1 < kChunk) {
+      p = predict(L);
+      d = sample(j + 1) - p;
+      m = d >> 31;
+      f = (float)d;
+      pin(m);
+      pin(f);
+    } else {
+      qd_out = qd;
+      pin_weights(L);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+/*
+ * Sixteen encoder steps for the quad mapping.  With the LMS and the prediction down to a few
+ * instructions the two dependent LDS lookups of encode_chunk16 would bound the sample (~190
+ * cycles); here the index delta is arithmetic, so the only lookup on the recurrence is the next
+ * step record, started right after the quantiser and hidden behind everything else:
+ *   A  quantise, delta, new step index; start the lookup of the next sample's step record
+ *   B  dequantise, reconstruct, LMS, history shift, pack the code, predict + difference of the next sample
+ */
+struct EncodeCarry {
+  u32x3 e;         /* {step, hr, hs} of the coming sample */
+  int32_t p, d, m; /* its prediction, difference and sign mask */
+  float f;         /* (float)d */
+};
+
+template <int BITS>
+__device__ __forceinline__ void encode_prime_quad(QuadLane &L, EncodeCarry &C, int32_t x0, const char *lds)
+{
+  C.e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
+  C.p = predict(L);
+  C.d = x0 - C.p;
+  C.m = C.d >> 31;
+  C.f = (float)C.d;
+}
+
+/* x: this chunk's 16 samples, xn0: the first sample of the next chunk (the pipeline is carried
+ * from chunk to chunk like the decoder's, see DecodeCarry) */
+/* PACKED: x holds the chunk as eight dwords of two int16 samples each (and xn0 the next chunk's
+ * first such dword) instead of sixteen sign-extended values */
+template <int BITS, bool EMIT, bool PACKED = false>
+__device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C, const int32_t *x, int32_t xn0,
+                                                    const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq)
+{
+  auto sample = [&](int k) -> int32_t { /* sample k of this chunk (k = 16: first of the next), k compile-time */
+    if (PACKED) {
+      const int32_t word = k < kChunk ? x[k >> 1] : xn0;
+      return (k & 1) ? word >> 16 : (int32_t)(int16_t)word;
+    }
+    return k < kChunk ? x[k] : xn0;
+  };
+  u32x3 e = C.e;
+  int32_t p = C.p, d = C.d, m = C.m;
+  float f = C.f;
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    /* A */
+    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)),
+                             Pack<BITS>::kMagMax);
+    const uint32_t step2_j = e.x; /* 2 * step (stage_tables<.., WIDE_STEP_SHIFT = 1>) */
+    L.idxb = clamp_idx(L.idxb + index_delta_arith<BITS>(mag));
+    e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
+    __builtin_amdgcn_sched_barrier(0);
+    /* B: q = (step * (2 mag + 1)) >> (BITS-1) as ONE high multiply:
+     * (2 step) * ((2 mag + 1) << (32 - BITS)) = step * (2 mag + 1) * 2^(33 - BITS), upper 32 bits.
+     * 2 step < 2^16 and (2 mag + 1) < 2^BITS, so neither factor overflows and the result is exact. */
+    const uint32_t m21s = (mag << (33 - BITS)) | (1u << (32 - BITS));
+    const int32_t q = (int32_t)__umulhi(step2_j, m21s);
+    const int32_t qd = (q ^ m) - m;
+    const int32_t y = clip16(qd + p);
+    lms_and_shift(L, qd, y);
+    /* prediction of the next sample, with the two instructions that pack this sample's code
+     * placed in the wait states its DPP adds need (see decode_chunk16_quad) */
+    uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
+    pin(s);
+    uint32_t code = 0, sqw = 0;
+    if (EMIT) {
+      code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
+      pin(code);
+    } else {
+      sqw = (uint32_t)qd * (uint32_t)qd;
+      pin(sqw);
+    }
+    s += quad_dpp<0xB1>(s);
+    pin(s);
+    if (EMIT) {
+      uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
+      acc = (acc << BITS) | code; /* v_lshl_or_b32 */
+      pin(acc);
+    } else {
+      sq += (int64_t)(int32_t)sqw;
+    }
+    s += quad_dpp<0x4E>(s);
+    p = (int32_t)s >> 15;
+    d = sample(j + 1) - p;
+    m = d >> 31;
+    f = (float)d;
+    pin(m);
+    pin(f);
+    if (j + 1 == kChunk) qd_out = qd;
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  C.e = e;
+  C.p = p;
+  C.d = d;
+  C.m = m;
+  C.f = f;
+}
+
+/* ================================================================================ encode == */
+
+struct EncodeArgs {
+  const StreamDesc *streams;
+  const int16_t *pcm;
+  uint8_t *data;
+  LaneStateRecord *state; /* may be null */
+  uint32_t num_streams;
+  uint32_t channels;
+  uint32_t block_size;
+  uint32_t samples_per_block;
+  uint32_t mid_side;
+  uint32_t trials;
+  uint32_t bits;
+  UniformLayout uni;
+  uint8_t header_template[32]; /* 31-byte file header with num_samples = 0 */
+};
+
+/* sample i of channel c of a stream, after the optional L/R -> M/S transform
+ * (reference src/aad_encoder.c:413-428; the clip there can never trigger for int16 input) */
+template <bool MS>
+struct SampleSource {
+  const int16_t *x;
+  uint32_t ch, c;
+  __device__ __forceinline__ int32_t at(uint64_t i) const
+  {
+    if (MS) {
+      const int32_t l = x[i * 2], r = x[i * 2 + 1];
+      return c == 0 ? (l + r) >> 1 : (l - r) >> 1;
+    }
+    return x[i * ch + c];
+  }
+};
+
+/* 16 consecutive samples of channel c starting at frame `first`, fetched with wide loads.
+ * CHF = 1: 32 contiguous bytes; CHF = 2: 64 bytes of L/R frames (both lanes of the pair read
+ * the same bytes and keep their own half); CHF = 0: 16 strided int16 loads. */
+template <int CHF, bool MS>
+struct ChunkSamples {
+  uint32_t d[CHF == 1 ? 8 : 16];
+  __device__ __forceinline__ void load(const int16_t *x, uint32_t ch, uint32_t c)
+  {
+    if (CHF == 1) {
+      const u32x4 a = reinterpret_cast<const U32x4 *>(x)->v, b = reinterpret_cast<const U32x4 *>(x + 8)->v;
+      d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    } else if (CHF == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32x4 a = reinterpret_cast<const U32x4 *>(x + 8 * k)->v;
+        d[4 * k] = a.x; d[4 * k + 1] = a.y; d[4 * k + 2] = a.z; d[4 * k + 3] = a.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) d[k] = (uint32_t)(int32_t)x[(uint32_t)k * ch + c];
+    }
+  }
+  /* see ChunkCodes::touch */
+  __device__ __forceinline__ void touch()
+  {
+    constexpr int n = CHF == 1 ? 8 : 16;
+    asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]) :: "memory");
+    if (n == 16)
+      asm volatile("" : "+v"(d[n - 8]), "+v"(d[n - 7]), "+v"(d[n - 6]), "+v"(d[n - 5]), "+v"(d[n - 4]), "+v"(d[n - 3]),
+                        "+v"(d[n - 2]), "+v"(d[n - 1]) :: "memory");
+  }
+  /* samples 2k and 2k+1 of channel c as one dword (low half first): what the quad encoder keeps
+   * per chunk - its subtract reads the halves directly (SDWA), no per-sample extraction */
+  __device__ __forceinline__ uint32_t pair(int k, uint32_t sel) const
+  {
+    if (CHF == 1) return d[k];
+    return __builtin_amdgcn_perm(d[2 * k + 1], d[2 * k], sel); /* sel = c ? 0x07060302 : 0x05040100 */
+  }
+  __device__ __forceinline__ int32_t get(int j, uint32_t c) const
+  {
+    if (CHF == 1) return __builtin_amdgcn_sbfe((int32_t)d[j >> 1], (j & 1) * 16, 16);
+    if (CHF == 2) {
+      if (MS) {
+        const int32_t l = __builtin_amdgcn_sbfe((int32_t)d[j], 0, 16), r = (int32_t)d[j] >> 16;
+        return c == 0 ? (l + r) >> 1 : (l - r) >> 1;
+      }
+      return __builtin_amdgcn_sbfe((int32_t)d[j], c * 16, 16);
+    }
+    return (int32_t)d[j];
+  }
+};
+
+template <typename Src>
+__device__ __forceinline__ void seed_history(Lane &L, const Src &src, uint64_t first, uint32_t n)
+{
+  L.h3 = n > 0 ? src.at(first + 0) : 0;
+  L.h2 = n > 1 ? src.at(first + 1) : 0;
+  L.h1 = n > 2 ? src.at(first + 2) : 0;
+  L.h0 = n > 3 ? src.at(first + 3) : 0;
+}
+template <typename Src>
+__device__ __forceinline__ void seed_history(QuadLane &Q, const Src &src, uint64_t first, uint32_t n, uint32_t tap)
+{
+  const uint32_t k = 3u - tap; /* tap t holds the sample that is t steps old: h_t = x[3 - t] */
+  Q.h = k < n ? src.at(first + k) : 0;
+}
+
+__device__ __forceinline__ void store_be16(uint8_t *p, uint32_t v)
+{
+  p[0] = (uint8_t)(v >> 8);
+  p[1] = (uint8_t)v;
+}
+
+/* block header of one channel - reference src/aad_encoder.c:619-655.  Drops the weight bits the
+ * 16-bit header fields cannot carry from the lane's own state as well. */
+__device__ __forceinline__ void write_block_header(Lane &L, uint8_t *p, bool do_store)
+{
+  auto wabs = [](int32_t w) { const int32_t m = w >> 31; return (int32_t)(((uint32_t)w ^ (uint32_t)m) - (uint32_t)m); };
+  const int32_t maxabs = max(max(max(wabs(L.w0), wabs(L.w1)), max(wabs(L.w2), wabs(L.w3))), 0);
+  const int32_t shift = max(17 - (int32_t)__clz(maxabs), 0); /* smallest shift with maxabs >> shift <= 32767 */
+  const int32_t mask = (int32_t)~((1u << shift) - 1u);
+  L.w0 &= mask;
+  L.w1 &= mask;
+  L.w2 &= mask;
+  L.w3 &= mask;
+  if (!do_store) return;
+  store_be16(p, ((((uint32_t)(L.idxb - kIdxBias)) << 4) & 0xFFFFu) | ((uint32_t)shift & 0xFu));
+  store_be16(p + 2, (uint32_t)(L.w0 >> shift));
+  store_be16(p + 4, (uint32_t)L.h0);
+  store_be16(p + 6, (uint32_t)(L.w1 >> shift));
+  store_be16(p + 8, (uint32_t)L.h1);
+  store_be16(p + 10, (uint32_t)(L.w2 >> shift));
+  store_be16(p + 12, (uint32_t)L.h2);
+  store_be16(p + 14, (uint32_t)(L.w3 >> shift));
+  store_be16(p + 16, (uint32_t)L.h3);
+}
+
+/* Write the packed codes of one 16-sample chunk.  w[]: big-endian code words of this lane's
+ * channel.  up: first byte of the chunk's first unit of channel 0.  For stereo the two lanes of
+ * a pair trade one word through DPP and each writes half of the interleaved bytes. */
+template <int BITS, int CHF, bool QUAD>
+__device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w, uint32_t c)
+{
+  if (CHF == 1) {
+    if (BITS == 4) {
+      u32x2 v;
+      v.x = perm(0, w[0], 0x00010203);
+      v.y = perm(0, w[1], 0x00010203);
+      reinterpret_cast<U32x2 *>(up)->v = v;
+    } else if (BITS == 2) {
+      reinterpret_cast<U32 *>(up)->v = perm(0, w[0], 0x00010203);
+    } else { /* a0 a1 a2 a3 | a4 a5 : w0 = 0 a0 a1 a2, w1 = 0 a3 a4 a5 */
+      reinterpret_cast<U32 *>(up)->v = perm(w[1], w[0], 0x06000102);
+      reinterpret_cast<U16 *>(up + 4)->v = (uint16_t)perm(0, w[1], 0x0c0c0001);
+    }
+  } else { /* stereo */
+    if (BITS == 2) { /* out: a0 b0 a1 b1 | a2 b2 a3 b3 ; lane c writes dword c */
+      const uint32_t other = pair_swap<QUAD>(w[0], c);
+      const uint32_t A = c ? other : w[0], B = c ? w[0] : other; /* A = channel 0 word, B = channel 1 word */
+      reinterpret_cast<U32 *>(up + 4 * c)->v = perm(A, B, c ? 0x00040105u : 0x02060307u);
+    } else {
+      /* lane 0 writes the first half (needs word 0 of both channels), lane 1 the second half */
+      const uint32_t send = c ? w[0] : w[1], keep = c ? w[1] : w[0];
+      const uint32_t recv = pair_swap<QUAD>(send, c);
+      const uint32_t A = c ? recv : keep, B = c ? keep : recv;
+      if (BITS == 4) { /* a0 b0 a1 b1 | a2 b2 a3 b3 from A = a0 a1 a2 a3, B = b0 b1 b2 b3 (big-endian words) */
+        u32x2 v;
+        v.x = perm(A, B, 0x02060307);
+        v.y = perm(A, B, 0x00040105);
+        reinterpret_cast<U32x2 *>(up + 8 * c)->v = v;
+      } else { /* a0 a1 a2 b0 | b1 b2 from A = 0 a0 a1 a2, B = 0 b0 b1 b2 */
+        reinterpret_cast<U32 *>(up + 6 * c)->v = perm(A, B, 0x02040506);
+        reinterpret_cast<U16 *>(up + 6 * c + 4)->v = (uint16_t)perm(A, B, 0x0c0c0001);
+      }
+    }
+  }
+}
+
+/*
+ * One pass of the recurrence over the coded samples of a block: samples [first+4, first+n) of
+ * channel c, history already seeded.  EMIT = the real encode pass (codes packed and stored under
+ * `body`); otherwise an RMSE pass of the trial search (reference src/aad_encoder.c:431-467): the
+ * same arithmetic, the int32-wrapped squares of the dequantised differences summed instead of any
+ * output (every partial sum is an exact integer < 2^53, so an int64 sum converted once equals
+ * the reference's running double).  Full 16-sample chunks go through the hand-pipelined bodies
+ * with wide prefetched loads, the rest through encode_step.
+ */
+template <int BITS, int CHF, bool MS, bool QUAD, bool EMIT, typename S>
+__device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t ch,
+                                             uint32_t c, bool writer, uint8_t *body, const char *lds, int32_t &last_qd)
+{
+  constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
+  const uint32_t unit_stride = UB * ch;
+  const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
+  int64_t sq = 0;
+  uint32_t done = 0;
+  {
+    using CS = ChunkSamples<CHF, MS>;
+    const uint32_t full = coded / kChunk;
+    const int16_t *xp = src.x + (first + kTaps) * ch;
+    constexpr uint32_t kOutStride = Pack<BITS>::kChunkBytes;
+    CS next;
+    for (auto &v : next.d) v = 0;
+    if (full) next.load(xp, ch, c);
+    next.touch();
+    if constexpr (QUAD) {
+      /* pipeline carried across chunks: chunk k+1's samples are extracted one chunk early.
+       * Without M/S they stay packed two to a dword (kN = 8 registers per chunk); the M/S
+       * transform needs them widened (kN = 16). */
+      constexpr bool PK = !MS;
+      constexpr int kN = PK ? kChunk / 2 : kChunk;
+      const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
+      auto extract = [&](int32_t(&dst)[kN]) {
+#pragma unroll
+        for (int j = 0; j < kN; j++) dst[j] = PK ? (int32_t)next.pair(j, pair_sel) : next.get(j, c);
+      };
+      auto first_sample = [&](const int32_t(&buf)[kN]) -> int32_t { return PK ? (int32_t)(int16_t)buf[0] : buf[0]; };
+      int32_t x[kN], xn[kN];
+      EncodeCarry C;
+      if (full) {
+        extract(x);
+        if (full > 1) xp += (uint64_t)kChunk * ch;
+        next.load(xp, ch, c);
+        next.touch();
+        extract(xn);
+        encode_prime_quad<BITS>(L, C, first_sample(x), lds);
+      }
+      /* x and xn swap roles every chunk (the loop is unrolled by two) so that the samples of
+       * chunk k+2 are extracted straight into the buffer chunk k has just freed - rotating the
+       * buffers with moves cost 30 instructions per chunk */
+      auto one = [&](uint32_t k, int32_t(&cur)[kN], const int32_t(&ahead)[kN]) {
+        if (k + 2 < full) xp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
+        next.load(xp, ch, c);
+        uint32_t w[2] = {0, 0};
+        encode_chunk16_quad<BITS, EMIT, PK>(L, C, cur, ahead[0], lds, w, last_qd, sq);
+        next.touch();
+        extract(cur);
+        if (EMIT && writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD>(body + (uint64_t)k * kOutStride * ch, w, c);
+      };
+      for (uint32_t k = 0; k < full; k += 2) {
+        one(k, x, xn);
+        if (k + 1 < full) one(k + 1, xn, x);
+      }
+    } else {
+      /* mono / stereo without M/S: the samples stay packed two to a dword (see encode_chunk16) */
+      constexpr bool PK = CHF != 0 && !MS;
+      constexpr int kN = PK ? kChunk / 2 : kChunk;
+      const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
+      for (uint32_t k = 0; k < full; k++) {
+        int32_t x[kN];
+#pragma unroll
+        for (int j = 0; j < kN; j++) x[j] = PK ? (int32_t)next.pair(j, pair_sel) : next.get(j, c);
+        /* unconditional prefetch (the last iteration re-reads its own chunk), see the decoder */
+        if (k + 1 < full) xp += (uint64_t)kChunk * ch;
+        next.load(xp, ch, c);
+        uint32_t w[2] = {0, 0};
+        encode_chunk16<BITS, EMIT, PK>(L, x, lds, w, last_qd, sq);
+        next.touch();
+        if (EMIT) {
+          if (CHF != 0) {
+            store_chunk_codes<BITS, (CHF ? CHF : 1), false>(body + (uint64_t)k * kOutStride * ch, w, c);
+          } else { /* any channel count: this lane's unit bytes one by one */
+            uint8_t *up = body + (uint64_t)k * kOutStride * ch + (uint64_t)c * UB;
+#pragma unroll
+            for (int u = 0; u < kChunk / US; u++) {
+              const int per_word = Pack<BITS>::kCodesPerWord / US; /* units per code word */
+              const uint32_t word = w[u / per_word];
+              const uint32_t unit = word >> (8 * UB * (per_word - 1 - (u % per_word)));
+#pragma unroll
+              for (int q = 0; q < UB; q++) up[(uint64_t)u * unit_stride + q] = (uint8_t)(unit >> (8 * (UB - 1 - q)));
+            }
+          }
+        }
+      }
+    }
+    done = full * kChunk;
+  }
+
+  if (EMIT) { /* tail units: samples past n are zero padding - reference :592-593 */
+    uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
+    for (uint32_t i = done; i < coded; i += US, up += unit_stride) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < US; k++) {
+        const int32_t x = i + k < coded ? src.at(first + kTaps + i + k) : 0;
+        acc = (acc << BITS) | encode_step<BITS>(L, x, lds, last_qd);
+      }
+      if (writer) {
+#pragma unroll
+        for (int k = 0; k < UB; k++) up[k] = (uint8_t)(acc >> (8 * (UB - 1 - k)));
+      }
+    }
+  } else { /* an RMSE pass stops at the last real sample (reference :457) */
+    for (uint32_t i = done; i < coded; i++) {
+      int32_t qd;
+      encode_step<BITS>(L, src.at(first + kTaps + i), lds, qd);
+      sq += wrapped_square(qd);
+    }
+  }
+  return sq;
+}
+
+/* RMSE of the dequantised differences over one block while the lane adapts - reference
+ * src/aad_encoder.c:431-467 (divisor = the block length, sum over the coded samples only) */
+template <int BITS, int CHF, bool MS, bool QUAD, typename S>
+__device__ __forceinline__ double rmse_pass(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t ch,
+                                            uint32_t c, uint32_t tap, const char *lds)
+{
+  if (n < (uint32_t)kTaps) return 0.0;
+  if constexpr (QUAD) seed_history(L, src, first, n, tap); else seed_history(L, src, first, n);
+  int32_t qd_unused = 0;
+  const int64_t sum = run_block<BITS, CHF, MS, QUAD, false>(L, src, first, n, ch, c, false, nullptr, lds, qd_unused);
+  return sqrt((double)sum / (double)n);
+}
+
+/* trial search - reference src/aad_encoder.c:470-562 (per channel; channels are independent) */
+template <int BITS, int CHF, bool MS, bool QUAD, typename S>
+__device__ __forceinline__ void search_best_lane(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t spb,
+                                                 uint32_t trials, uint32_t ch, uint32_t c, uint32_t tap, const char *lds)
+{
+  const bool have_prev = first >= spb;
+  S best = L, run = L;
+  double best_rmse = 0.0;
+  /* One call site for every pass (the pipelined chunk bodies exist once in the kernel):
+   * pass 0 is the probe, then per trial [previous block,] current block.  Without a previous
+   * block the probe and trial 0 are the same computation from the same state - equal RMSE, no
+   * strict improvement - so it is run once (first block of every stream: 1 + t passes, not 2 + t). */
+  const uint32_t per_trial = have_prev ? 2u : 1u;
+  const uint32_t passes = have_prev ? 1u + 2u * trials : trials;
+  for (uint32_t p = 0; p < passes; p++) {
+    const bool is_probe = have_prev && p == 0;
+    const bool on_prev = have_prev && p != 0 && ((p - 1u) % per_trial) == 0;
+    S from = is_probe ? L : run;
+    const S before = from;
+    const double r = rmse_pass<BITS, CHF, MS, QUAD>(from, src, on_prev ? first - spb : first, on_prev ? spb : n, ch, c, tap, lds);
+    if (!is_probe) run = from;
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if (is_probe || (!have_prev && p == 0)) {
+      best_rmse = r;
+    } else if (!on_prev && best_rmse > r) {
+      best_rmse = r;
+      best = before;
+    }
+  }
+  L = best;
+}
+
+/*
+ * The same search with its two independent strands on different lanes ("dual" mapping, used
+ * with the quad mapping, i.e. when lanes are idle anyway).  The reference evaluates
+ *   probe:  RMSE of the current block from the carried state                      (1 pass)
+ *   chain:  trials x ([previous block] + current block), each from where the last ended
+ * one after the other: 2 + 2t passes per block with the final encode.  The probe does not feed
+ * the chain, so a second group of four lanes (role 1) runs it while role 0 runs the chain's
+ * first pass; role 0 then finishes the chain alone, picks the winner exactly as the reference
+ * does (strict >, probe first) and encodes: 1 + 2t passes of latency.  One call site for every
+ * pass keeps the pipelined chunk bodies in the kernel once.
+ */
+template <int BITS, int CHF, bool MS, typename S>
+__device__ __forceinline__ void search_best_lane_dual(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t spb,
+                                                      uint32_t trials, uint32_t ch, uint32_t c, uint32_t tap, uint32_t role,
+                                                      const char *lds)
+{
+  const bool have_prev = first >= spb;
+  const uint32_t chain_passes = trials * (have_prev ? 2u : 1u);
+  S best = L, run = L;
+  double best_rmse = 0.0;
+  for (uint32_t p = 0; p < chain_passes; p++) {
+    const bool on_prev = role == 0 && have_prev && (p & 1u) == 0;
+    const bool active = role == 0 || p == 0;
+    double r = 0.0;
+    S before = run;
+    if (active) r = rmse_pass<BITS, CHF, MS, true>(run, src, on_prev ? first - spb : first, on_prev ? spb : n, ch, c, tap, lds);
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if (p == 0) { /* the probe's figure moves over to the chain's lanes (role 1 sits CHF quads above role 0) */
+      const int from = (int)((threadIdx.x & 63u) + (role == 0 ? 4u * (CHF ? CHF : 1) : 0u));
+      best_rmse = __shfl(r, from, 64);
+    }
+    if (role == 0 && !on_prev && best_rmse > r) {
+      best_rmse = r;
+      best = before;
+    }
+  }
+  L = best; /* role 1 is handed role 0's state again after the block's encode pass */
+}
+
+/*
+ * Stream-parallel encode (reference src/aad_encoder.c:814-891 with EncodeBlock :565-727 and the
+ * optional trial search :470-562 inlined).  lane = (stream, channel).
+ */
+template <int BITS, int CHF, bool MS, bool QUAD, bool TRIALS, bool DUAL = false>
+__global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
+{
+  static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
+  static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
+  __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+  stage_tables<BITS, QUAD, 1>(lds);
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+
+  const uint32_t ch = CHF ? CHF : a.channels;
+  const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  /* dual: with trials on the quad mapping every stream owns 2 x CHF quads, laid out
+   * [role 0: ch 0 .. CHF-1][role 1: ch 0 .. CHF-1] so that a stereo pair stays 4 lanes apart */
+  constexpr uint32_t kQuadsPerStream = DUAL ? 2u * (CHF ? CHF : 1) : 1u;
+  const uint32_t role = DUAL ? (uint32_t)((thread >> 2) % kQuadsPerStream) / (CHF ? CHF : 1) : 0u;
+  const uint64_t lane = DUAL ? (thread >> 2) / kQuadsPerStream * (CHF ? CHF : 1) + (thread >> 2) % (CHF ? CHF : 1)
+                             : (QUAD ? thread >> 2 : thread); /* index of the (stream, channel) recurrence */
+  const uint32_t tap = QUAD ? threadIdx.x & 3u : 0u;
+  const bool writer = tap == 0 && role == 0;         /* quad: all four lanes hold the codes, one stores them */
+  if (lane >= (uint64_t)a.num_streams * ch) return; /* whole quads / stereo pairs / role groups leave together */
+  const uint32_t s = (uint32_t)(lane / ch), c = (uint32_t)(lane % ch);
+  const StreamDesc sd = a.uni.enabled ? uniform_stream(a.uni, s) : a.streams[s];
+  const SampleSource<MS> src = {a.pcm + sd.pcm_offset, ch, c};
+  uint8_t *out = a.data + sd.data_offset;
+  const uint32_t total = sd.num_samples, spb = a.samples_per_block;
+
+  /* F: the complete per-channel state, the form block headers and the state records need;
+   * between block boundaries the quad mapping spreads it over four lanes (S) */
+  using S = std::conditional_t<QUAD, QuadLane, Lane>;
+  Lane F = {0, 0, 0, 0, 0, 0, 0, 0, kIdxBias};
+  int32_t last_qd = 0;
+  if (a.state) {
+    const LaneStateRecord r = a.state[lane];
+    F = {r.weight[0], r.weight[1], r.weight[2], r.weight[3],
+         r.history[0], r.history[1], r.history[2], r.history[3],
+         min(max(r.stepsize_index, 0), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias};
+    last_qd = r.quantize_error;
+  }
+
+  if (c == 0 && writer) { /* file header - reference src/aad_encoder.c:190-214 */
+    for (int i = 0; i < kFileHeaderBytes; i++) out[i] = a.header_template[i];
+    out[14] = (uint8_t)(total >> 24);
+    out[15] = (uint8_t)(total >> 16);
+    out[16] = (uint8_t)(total >> 8);
+    out[17] = (uint8_t)total;
+  }
+
+  uint64_t block_off = kFileHeaderBytes;
+  for (uint64_t first = 0; first < total; first += spb, block_off += a.block_size) {
+    const uint32_t n = total - first < spb ? (uint32_t)(total - first) : spb;
+    S L;
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if constexpr (TRIALS) { /* reference src/aad_encoder.c:863-871; a separate instantiation so that the
+                             * trial-free kernel does not carry the search's registers */
+      if constexpr (QUAD) L = to_quad(F, tap); else L = F;
+      if constexpr (DUAL) search_best_lane_dual<BITS, CHF, MS>(L, src, first, n, spb, a.trials, ch, c, tap, role, lds);
+      else search_best_lane<BITS, CHF, MS, QUAD>(L, src, first, n, spb, a.trials, ch, c, tap, lds);
+      if constexpr (QUAD) F = from_quad(L); else F = L;
+    }
+    seed_history(F, src, first, n);
+    write_block_header(F, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh, writer);
+    if constexpr (QUAD) L = to_quad(F, tap); else L = F;
+    uint8_t *body = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch;
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if (role == 0) {
+      (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd);
+      if constexpr (QUAD) F = from_quad(L); else F = L;
+    }
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if constexpr (DUAL) { /* the probe lanes start the next block from the encoder's state */
+      const int from = (int)((threadIdx.x & 63u) - role * 4u * (CHF ? CHF : 1));
+      F.w0 = __shfl(F.w0, from, 64); F.w1 = __shfl(F.w1, from, 64); F.w2 = __shfl(F.w2, from, 64); F.w3 = __shfl(F.w3, from, 64);
+      F.h0 = __shfl(F.h0, from, 64); F.h1 = __shfl(F.h1, from, 64); F.h2 = __shfl(F.h2, from, 64); F.h3 = __shfl(F.h3, from, 64);
+      F.idxb = __shfl(F.idxb, from, 64);
+      last_qd = __shfl(last_qd, from, 64);
+    }
+  }
+
+  if (a.state && writer) {
+    LaneStateRecord r;
+    r.weight[0] = F.w0; r.weight[1] = F.w1; r.weight[2] = F.w2; r.weight[3] = F.w3;
+    r.history[0] = F.h0; r.history[1] = F.h1; r.history[2] = F.h2; r.history[3] = F.h3;
+    r.stepsize_index = F.idxb - kIdxBias;
+    r.quantize_error = last_qd;
+    a.state[lane] = r;
+  }
+}
+
+} /* namespace aad */
+
+#endif /* AAD_ENCODE_HIP_H */

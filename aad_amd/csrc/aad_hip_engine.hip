@@ -1,7 +1,8 @@
 /*
  * aad_hip_engine.hip - host side of the batched C-ABI declared in include/aad_hip.h:
  * contexts, plans (uploaded stream tables), kernel launches and the host-memory convenience
- * calls.  Device code lives in aad_device.hip.h.  gfx950 only; there is no CPU code path -
+ * calls.  Device code lives in aad_encode.hip.h / aad_decode.hip.h (shared parts: aad_device.hip.h)
+ * and, for the split decoder, in its own unit aad_decode_split.hip.  gfx950 only; no CPU code path -
  * every entry point that needs the GPU fails with AAD_APIRESULT_NG when HIP does.
  */
 #include <hip/hip_runtime.h>
@@ -15,7 +16,8 @@
 #include "../../include/aad_hip.h"
 #include "aad_compare.hip.h"
 #include "aad_decode_split_launch.h"
-#include "aad_device.hip.h"
+#include "aad_decode.hip.h"
+#include "aad_encode.hip.h"
 #include "aad_format.h"
 #include "aad_hip_internal.h"
 

@@ -1,5 +1,5 @@
 """The HIP encoder replaces the quantiser's integer division by convert / fma / truncate
-(aad_amd/csrc/aad_device.hip.h encode_step).  tests/quantiser_equiv.c proves the two equal for
+(aad_amd/csrc/aad_encode.hip.h encode_step).  tests/quantiser_equiv.c proves the two equal for
 every reachable operand; the GPU side of the same claim is covered by the parity tests."""
 import os
 import subprocess
