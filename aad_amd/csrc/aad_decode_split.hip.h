@@ -262,7 +262,7 @@ __device__ __forceinline__ void predict_chunk16_quad(QuadLane &L, PredictCarry &
  * CHF = 1 or 2 (the quad mapping exists for mono / stereo only).
  */
 template <int CHF, bool MS>
-__device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint64_t thread, const int32_t *res)
+__device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint64_t thread, const int32_t *res, uint32_t *stage)
 {
   constexpr uint32_t ch = CHF;
   const uint64_t rec = thread >> 2;
@@ -326,18 +326,63 @@ __device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint6
       b1.load(rp);
       predict_prime(L, C, b0.get(0));
     }
+    /* Stereo output.  All four lanes of a quad hold the same sixteen samples and the two quads of
+     * a block sit side by side, so the L/R interleave is shared out over the block's eight lanes
+     * instead of being done by the two tap-0 lanes with DPP swaps: every lane packs its chunk
+     * into eight dwords and drops them into a 1 KB LDS staging area (two buffers, this wave's
+     * sixteen rows), and one chunk later - no LDS round trip to wait for - lane (channel, tap)
+     * picks dword 4 * channel + tap of the block's L row and of its R row and stores those two
+     * frames: eight lanes x 8 bytes = the chunk's 64 contiguous bytes.  17 instruction slots per
+     * chunk instead of 36. */
+    constexpr bool COOP = CHF == 2;
+    const uint32_t quad = (threadIdx.x & 63u) >> 2;
+    const uint32_t part = threadIdx.x & 7u; /* = 4 * channel + tap */
+    uint32_t *my_row = stage + quad * 8u;
+    const uint32_t *l_row = stage + (quad & ~1u) * 8u + part, *r_row = l_row + 8;
+    auto stage_chunk = [&](uint32_t k, const int32_t *y) {
+      u32x4 lo, hi;
+      lo.x = perm((uint32_t)y[1], (uint32_t)y[0], 0x05040100);
+      lo.y = perm((uint32_t)y[3], (uint32_t)y[2], 0x05040100);
+      lo.z = perm((uint32_t)y[5], (uint32_t)y[4], 0x05040100);
+      lo.w = perm((uint32_t)y[7], (uint32_t)y[6], 0x05040100);
+      hi.x = perm((uint32_t)y[9], (uint32_t)y[8], 0x05040100);
+      hi.y = perm((uint32_t)y[11], (uint32_t)y[10], 0x05040100);
+      hi.z = perm((uint32_t)y[13], (uint32_t)y[12], 0x05040100);
+      hi.w = perm((uint32_t)y[15], (uint32_t)y[14], 0x05040100);
+      uint32_t *dst = my_row + (k & 1u) * 128u;
+      *reinterpret_cast<u32x4 *>(dst) = lo;
+      *reinterpret_cast<u32x4 *>(dst + 4) = hi;
+    };
+    auto flush_chunk = [&](uint32_t k, uint32_t l, uint32_t r) { /* frames 2 * part, 2 * part + 1 of chunk k */
+      u32x2 v;
+      v.x = perm(r, l, 0x05040100);
+      v.y = perm(r, l, 0x07060302);
+      reinterpret_cast<U32x2 *>(op + (uint64_t)k * kChunk * ch + 4u * part)->v = v;
+    };
     auto one = [&](uint32_t k, const ChunkResiduals &cur, const ChunkResiduals &ahead, ChunkResiduals &incoming) {
       if (k + 2 < full) rp += kChunk; /* prefetch chunk k+2 (clamped to the last full one) */
       incoming.load(rp);
+      uint32_t l = 0, r = 0;
+      if (COOP && k) { /* the previous chunk's two staged dwords: requested now, used after this chunk's arithmetic */
+        l = l_row[((k - 1) & 1u) * 128u];
+        r = r_row[((k - 1) & 1u) * 128u];
+      }
       int32_t y[kChunk];
       predict_chunk16_quad(L, C, cur, ahead.get(0), y, finish);
-      if (writer) store_chunk_pcm<CHF, true>(op, y, c, ch);
-      op += (uint64_t)kChunk * ch;
+      if constexpr (COOP) {
+        stage_chunk(k, y);
+        if (k) flush_chunk(k - 1, l, r);
+      } else {
+        if (writer) store_chunk_pcm<CHF, true>(op + (uint64_t)k * kChunk * ch, y, c, ch);
+      }
     };
     for (uint32_t k = 0; k < full; k += 3) {
       one(k, b0, b1, b2);
       if (k + 1 < full) one(k + 1, b1, b2, b0);
       if (k + 2 < full) one(k + 2, b2, b0, b1);
+    }
+    if constexpr (COOP) {
+      if (full) flush_chunk(full - 1, l_row[((full - 1) & 1u) * 128u], r_row[((full - 1) & 1u) * 128u]);
     }
   }
   /* What is left of the block (fewer than 16 samples), one at a time.  The residuals are fetched
@@ -383,6 +428,7 @@ __global__ void __launch_bounds__(1024) decode_split_kernel(SplitDecodeArgs a)
   __shared__ uint32_t s_step[AAD_STEP_TABLE_LEN];
   __shared__ int32_t s_delta[8];
   __shared__ __attribute__((aligned(16))) int32_t s_res[LDSRES ? 16 * kLdsResidualRow : 4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[2 * 16 * 8]; /* stereo output staging of the recurrence wave */
   for (uint32_t i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) s_step[i] = c_step_table[i];
   if (threadIdx.x < 8) {
     const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
@@ -404,7 +450,8 @@ __global__ void __launch_bounds__(1024) decode_split_kernel(SplitDecodeArgs a)
   const bool active = rec < a.d.total_blocks * CHF;
   predict_for_quad<CHF, MS>(a, thread,
                             LDSRES ? s_res + (threadIdx.x >> 2) * kLdsResidualRow
-                                   : a.residual + (active ? rec : 0) * a.residual_stride);
+                                   : a.residual + (active ? rec : 0) * a.residual_stride,
+                            s_stage);
 }
 
 } /* namespace aad */
