@@ -7,11 +7,11 @@
  *   decode: lane = (block, channel)  - every block header reloads the whole state.
  * Adjacent lanes are the channels of one stream/block, so the bytes they touch are adjacent.
  *
- * What bounds these kernels (measured, tools/microbench, tools/phase_probe.py): every BASELINE
- * workload has far fewer recurrences than the chip has SIMD slots, and a lone gfx950 wave issues
- * one instruction per 4 cycles - one more when it reads the result of the instruction just before
- * it - whatever the instruction (VALU, SALU, LDS; 24- or 32-bit multiplies alike).  The lever is
- * therefore the NUMBER of instruction slots on the per-sample path, s_nop and s_waitcnt included:
+ * What bounds these kernels (measured, tools/microbench, tools/phase_probe.py,
+ * tools/experiments): every BASELINE workload has far fewer recurrences than the chip has SIMD
+ * slots, and a lone gfx950 wave issues one instruction per ~4.6 cycles whatever the instruction
+ * (VALU, SALU, DPP, LDS, s_nop, s_waitcnt; 24- or 32-bit multiplies alike) and whatever the
+ * order.  The lever is therefore the NUMBER of instruction slots on the per-sample path:
  *   - the whole per-channel state (4 weights, 4 history samples, step index) lives in VGPRs,
  *     history rotation is free because samples are processed in unrolled chunks of 16;
  *   - step size, fl32(0.5/step) and fl32(2^(b-1)*0.5/step) sit in LDS, fetched one sample ahead
