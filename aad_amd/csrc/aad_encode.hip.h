@@ -584,9 +584,10 @@ __device__ __forceinline__ void search_best_lane(S &L, const SampleSource<MS> &s
  *   chain:  trials x ([previous block] + current block), each from where the last ended
  * one after the other: 2 + 2t passes per block with the final encode.  The probe does not feed
  * the chain, so a second group of four lanes (role 1) runs it while role 0 runs the chain's
- * first pass; role 0 then finishes the chain alone, picks the winner exactly as the reference
- * does (strict >, probe first) and encodes: 1 + 2t passes of latency.  One call site for every
- * pass keeps the pipelined chunk bodies in the kernel once.
+ * first pass; after that pass role 1 copies role 0's state and shadows it (idle lanes cost
+ * nothing, switched-off lanes made the wave slower), the winner is picked exactly as the
+ * reference does (strict >, probe first), and both encode - role 0 alone stores: 1 + 2t passes
+ * of latency.  One call site for every pass keeps the pipelined chunk bodies in the kernel once.
  */
 template <int BITS, int CHF, bool MS, typename S>
 __device__ __forceinline__ void search_best_lane_dual(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t spb,
@@ -595,25 +596,33 @@ __device__ __forceinline__ void search_best_lane_dual(S &L, const SampleSource<M
 {
   const bool have_prev = first >= spb;
   const uint32_t chain_passes = trials * (have_prev ? 2u : 1u);
+  const int chain_lane = (int)((threadIdx.x & 63u) - role * 4u * (CHF ? CHF : 1)); /* role 0's lane of the same tap */
   S best = L, run = L;
   double best_rmse = 0.0;
   for (uint32_t p = 0; p < chain_passes; p++) {
-    const bool on_prev = role == 0 && have_prev && (p & 1u) == 0;
-    const bool active = role == 0 || p == 0;
-    double r = 0.0;
-    S before = run;
-    if (active) r = rmse_pass<BITS, CHF, MS, true>(run, src, on_prev ? first - spb : first, on_prev ? spb : n, ch, c, tap, lds);
+    /* pass 0: role 0 starts the chain, role 1 runs the probe.  From pass 1 on role 1 simply
+     * MIRRORS role 0 - same state, same window, same result: a wave with half of its lanes
+     * switched off ran these passes ~10 % slower than with all of them doing (redundant) work. */
+    const bool chain_on_prev = have_prev && (p & 1u) == 0;
+    const bool on_prev = chain_on_prev && !(p == 0 && role != 0);
+    const S before = run;
+    double r = rmse_pass<BITS, CHF, MS, true>(run, src, on_prev ? first - spb : first, on_prev ? spb : n, ch, c, tap, lds);
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
-    if (p == 0) { /* the probe's figure moves over to the chain's lanes (role 1 sits CHF quads above role 0) */
-      const int from = (int)((threadIdx.x & 63u) + (role == 0 ? 4u * (CHF ? CHF : 1) : 0u));
-      best_rmse = __shfl(r, from, 64);
+    if (p == 0) {
+      /* the probe's figure goes to both roles; role 1 takes over role 0's chain state and result */
+      const double probe = __shfl(r, chain_lane + (int)(4u * (CHF ? CHF : 1)), 64);
+      best_rmse = role == 0 ? probe : r;
+      r = __shfl(r, chain_lane, 64);
+      run.w = __shfl(run.w, chain_lane, 64);
+      run.h = __shfl(run.h, chain_lane, 64);
+      run.idxb = __shfl(run.idxb, chain_lane, 64);
     }
-    if (role == 0 && !on_prev && best_rmse > r) {
+    if (!chain_on_prev && best_rmse > r) {
       best_rmse = r;
-      best = before;
+      best = before; /* in pass 0 both roles started from L, so `before` is the chain's as well */
     }
   }
-  L = best; /* role 1 is handed role 0's state again after the block's encode pass */
+  L = best;
 }
 
 /*
@@ -685,18 +694,11 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
     if constexpr (QUAD) L = to_quad(F, tap); else L = F;
     uint8_t *body = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch;
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
-    if (role == 0) {
-      (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd);
-      if constexpr (QUAD) F = from_quad(L); else F = L;
-    }
+    /* dual: role 1 runs the encode pass as well (it holds the same state; only role 0 stores),
+     * which also leaves it with the right state for the next block */
+    (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd);
+    if constexpr (QUAD) F = from_quad(L); else F = L;
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
-    if constexpr (DUAL) { /* the probe lanes start the next block from the encoder's state */
-      const int from = (int)((threadIdx.x & 63u) - role * 4u * (CHF ? CHF : 1));
-      F.w0 = __shfl(F.w0, from, 64); F.w1 = __shfl(F.w1, from, 64); F.w2 = __shfl(F.w2, from, 64); F.w3 = __shfl(F.w3, from, 64);
-      F.h0 = __shfl(F.h0, from, 64); F.h1 = __shfl(F.h1, from, 64); F.h2 = __shfl(F.h2, from, 64); F.h3 = __shfl(F.h3, from, 64);
-      F.idxb = __shfl(F.idxb, from, 64);
-      last_qd = __shfl(last_qd, from, 64);
-    }
   }
 
   if (a.state && writer) {

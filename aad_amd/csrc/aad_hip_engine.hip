@@ -178,16 +178,14 @@ void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipSt
     hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS, false>), grid, block, 0, stream, a);
 }
 
-/* The trial search's probe strand gets lanes of its own ("dual") only where that pays: a masked
- * half-wave runs the chain's later passes ~10 % slower, and for the first block of a stream there
- * is no separate probe to overlap - so streams of three blocks and more (tools/phase_probe.py). */
-bool pick_dual(const aad::EncodeArgs &a, bool quad, uint64_t mean_blocks_per_stream)
+/* On the quad mapping the trial search's probe strand gets lanes of its own ("dual"): one pass of
+ * latency less per block with a predecessor, nothing lost otherwise (tools/trial_probe.py).
+ * AAD_HIP_TRIAL_LANES=single keeps both strands on the same lanes (the parity tests run both). */
+bool pick_dual(const aad::EncodeArgs &a, bool quad, uint64_t /*mean_blocks_per_stream*/)
 {
   if (!quad || a.trials == 0) return false;
   const char *e = getenv("AAD_HIP_TRIAL_LANES");
-  if (e != nullptr && strcmp(e, "dual") == 0) return true;
-  if (e != nullptr && strcmp(e, "single") == 0) return false;
-  return mean_blocks_per_stream >= 3;
+  return !(e != nullptr && strcmp(e, "single") == 0);
 }
 
 template <int BITS>
