@@ -24,7 +24,7 @@ def engine():
 
 
 @pytest.mark.parametrize("mapping", ["dense", "quad", "quad-fused", "auto"])
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(8))
 def test_random_parameter_sets(engine, mapping, seed):
     rng = np.random.default_rng(1000 + seed)
     if mapping == "auto":
