@@ -58,6 +58,44 @@ def host_api(eng, streams, samples, ch, bits, reps=5):
                 decode_ms=round(td * 1e3, 3), encode_msps=round(n / te / 1e6, 1), decode_msps=round(n / td / 1e6, 1))
 
 
+def pinned_end_to_end(eng, streams, samples, ch, bits, reps=20):
+    """Pinned host buffers -> H2D -> kernel -> D2H, all asynchronous on the engine's stream (what a
+    caller that owns pinned memory and device plans gets; no staging copies, no plan creation)."""
+    param = make_parameter(ch, bits, 1024, 48000, False, 0)
+    h_pcm = torch.from_numpy(synth_pcm(min(streams, 500), samples, ch, seed=7)).repeat((-(-streams // 500), 1, 1))[:streams].contiguous().pin_memory()
+    enc = eng.uniform_encode_plan(param, streams, samples)
+    d_pcm = torch.empty_like(h_pcm, device="cuda")
+    d_img = torch.zeros((streams, enc.stride), dtype=torch.uint8, device="cuda")
+    h_img = torch.empty((streams, enc.stride), dtype=torch.uint8).pin_memory()
+    h_out = torch.empty_like(h_pcm).pin_memory()
+    d_out = torch.empty_like(d_pcm)
+    d_pcm.copy_(h_pcm, non_blocking=True)
+    enc.run(d_pcm, d_img, None)
+    torch.cuda.synchronize()
+    hd = parse_header(bytes(d_img[0, :31].cpu().numpy()))
+    dec = eng.uniform_decode_plan(hd, streams, enc.stride, enc.image_size)
+    dec.run(d_img, d_out)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    te = td = 0.0
+    for _ in range(reps):
+        ev[0].record()
+        d_pcm.copy_(h_pcm, non_blocking=True)
+        enc.run(d_pcm, d_img, None)
+        h_img.copy_(d_img, non_blocking=True)
+        ev[1].record()
+        d_img.copy_(h_img, non_blocking=True)
+        dec.run(d_img, d_out)
+        h_out.copy_(d_out, non_blocking=True)
+        ev[2].record()
+        torch.cuda.synchronize()
+        te += ev[0].elapsed_time(ev[1]); td += ev[1].elapsed_time(ev[2])
+    n = streams * samples * ch
+    return dict(config="end to end from pinned memory (H2D + kernel + D2H) %d stereo x1 block" % streams,
+                encode_ms=round(te / reps, 4), decode_ms=round(td / reps, 4),
+                encode_msps=round(n / (te / reps) / 1e3, 1), decode_msps=round(n / (td / reps) / 1e3, 1))
+
+
 def main():
     eng = Engine(0)
     torch.cuda.set_stream(eng.stream)
@@ -70,6 +108,7 @@ def main():
             run(eng, "cfg5 shard 1250 files x10 blocks", 1250, 9920, 2, 4, reps=5),
             run(eng, "cfg5 all 10000 files x10 blocks", 10000, 9920, 2, 4, reps=3),
             run(eng, "cfg2 t=2", 1000, 992, 2, 4, trials=2),
+            pinned_end_to_end(eng, 1000, 992, 2, 4),
             host_api(eng, 1000, 992, 2, 4)]
     for r in rows:
         print(json.dumps(r))
