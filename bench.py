@@ -308,6 +308,14 @@ def main():
             "algorithmic_bytes_per_launch": int(round(n_step * bps)),
             "bytes_per_sample": round(bps, 4), "samples_per_launch": n_step,
             "kernel_ms": round(m["enc_ms"], 5), "hip_events": "on every %d-th step of the timed region" % args.event_every,
+            # what actually bounds a lane-starved launch (DESIGN.md "Kernels"): one wave per SIMD, one
+            # instruction slot per ~4 cycles.  35.0 slots per sample is the 4-bit stereo quad encoder's
+            # chunk loop counted in this build's ISA (560 per 16 samples, s_nop / s_waitcnt included).
+            "issue_bound": {"slots_per_sample": 35.0, "samples_per_recurrence": samples - 4,
+                            "achieved_Mslots_per_s_per_wave": round(35.0 * (samples - 4) / (m["enc_ms"] * 1e-3) / 1e6, 1),
+                            "peak_Mslots_per_s_per_wave": 600.0,
+                            "frac": round(35.0 * (samples - 4) / (m["enc_ms"] * 1e-3) / 600e6, 4),
+                            "note": "peak = 2.4 GHz / 4 cycles per wave64 instruction on a 16-lane SIMD; kernel_ms includes launch and prologue"},
             "decode_kernel": {"kernel": "aad::decode_split_kernel<4> (quad batches) / aad::decode_blocks_kernel<4> (dense)", "achieved": round(dec_gbs, 3),
                               "frac": round(dec_gbs / HBM_PEAK_GBS, 6), "kernel_ms": round(m["dec_ms"], 5)},
         },
