@@ -246,9 +246,12 @@ bool want_split_decode(const aad::DecodeArgs &a, uint64_t *bytes, uint32_t *stri
 {
   const uint64_t recurrences = a.total_blocks * a.channels;
   if (pick_decode_mapping(recurrences, a.channels) != DecodeMapping::QuadSplit) return false;
-  const uint32_t coded = a.samples_per_block > 4 ? a.samples_per_block - 4 : 0;
-  *stride = (coded + 15u) / 16u * 16u + 16u;
-  *bytes = recurrences * (uint64_t)*stride * sizeof(int32_t);
+  /* 64-bit: samples_per_block comes straight from a file header and may be anything */
+  const uint64_t coded = a.samples_per_block > 4 ? (uint64_t)a.samples_per_block - 4 : 0;
+  const uint64_t row = (coded + 15u) / 16u * 16u + 16u;
+  if (row > kMaxResidualBytes / sizeof(int32_t)) return false;
+  *stride = (uint32_t)row;
+  *bytes = recurrences * row * sizeof(int32_t);
   return *bytes <= kMaxResidualBytes; /* else the fused quad kernel */
 }
 

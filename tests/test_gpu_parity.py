@@ -405,3 +405,24 @@ def test_decode_mapping_ranges_auto(engine, streams, bits, ch):
     # every copy of a base stream decodes identically
     assert np.array_equal(dec[:500], dec[500:1000])
     assert np.array_equal(dec[streams - 500:], dec[(streams - 500) % 500:][:500]) if streams % 500 == 0 else True
+
+
+def test_inconsistent_header_geometry(engine, mapping):
+    """A header whose samples-per-block does not match its block size (nothing in the decoder's
+    checks forbids it, reference src/aad_decoder.c:173-225): one huge block claimed, far more
+    samples than the bytes can hold.  Bytes past the image read as zero here and in the oracle;
+    the point is that every decode path sizes its buffers from 64-bit arithmetic and survives."""
+    pcm = synth_pcm(1, 992, 2, seed=5)[0]
+    good = bytearray(ob.encode(pcm, 4, 1024))
+    for spb, n in ((1_000_000, 992), (1_000_000, 5000), (0xFFFFFFF0, 3000), (20, 992)):
+        img = bytearray(good)
+        img[14:18] = n.to_bytes(4, "big")          # num_samples
+        img[26:30] = spb.to_bytes(4, "big")        # num_samples_per_block
+        try:
+            want = ob.decode(bytes(img))[0]
+        except RuntimeError:
+            with pytest.raises(Exception):
+                engine.decode_host([bytes(img)])
+            continue
+        got = engine.decode_host([bytes(img)])[0]
+        assert np.array_equal(got, want), (spb, n)
