@@ -55,6 +55,9 @@ STREAM_DESC_DTYPE = np.dtype([("pcm_offset", "<u8"), ("data_offset", "<u8"), ("d
                               ("num_samples", "<u4"), ("reserved", "<u4")])
 ERROR_STATS_DTYPE = np.dtype([("rms_error", "<f8"), ("mean_abs_error", "<f8"), ("max_abs_error", "<f8")])  # AADHipErrorStats
 RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL = 0, 1  # enum AADHipReconstructOutput
+OPTION_LANE_MAPPING, OPTION_TRIAL_LANES = 0, 1  # enum AADHipOption
+LANE_MAPPINGS = {"auto": 0, "dense": 1, "quad": 2, "quad-fused": 3}  # enum AADHipLaneMapping
+TRIAL_LANES = {"dual": 0, "single": 1}  # enum AADHipTrialLanes
 LANE_STATE_DTYPE = np.dtype([("weight", "<i4", (4,)), ("history", "<i4", (4,)),
                              ("stepsize_index", "<i4"), ("quantize_error", "<i4")])
 
@@ -69,7 +72,7 @@ LEGACY_SYMBOLS = [
 ]
 HIP_SYMBOLS = [
     "AADHip_GetDeviceCount", "AADHip_ContextCreate", "AADHip_ContextDestroy", "AADHip_ContextSynchronize",
-    "AADHip_ContextLastError", "AADHip_CalculateEncodedSize", "AADHip_EncodePlanCreate",
+    "AADHip_ContextLastError", "AADHip_ContextSetOption", "AADHip_CalculateEncodedSize", "AADHip_EncodePlanCreate",
     "AADHip_EncodePlanDestroy", "AADHip_EncodePlanRun", "AADHip_DecodePlanCreate", "AADHip_DecodePlanDestroy",
     "AADHip_DecodePlanRun", "AADHip_EncodeBatch", "AADHip_DecodeBatch",
     "AADHip_ReconstructPlanCreate", "AADHip_ReconstructPlanDestroy", "AADHip_ReconstructPlanRun",
@@ -130,6 +133,8 @@ def _declare_hip(lib):
     lib.AADHip_ContextSynchronize.restype = C.c_int
     lib.AADHip_ContextLastError.argtypes = [vp]
     lib.AADHip_ContextLastError.restype = C.c_char_p
+    lib.AADHip_ContextSetOption.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.AADHip_ContextSetOption.restype = C.c_int
     lib.AADHip_CalculateEncodedSize.argtypes = [C.POINTER(AADEncodeParameter), C.c_uint32]
     lib.AADHip_CalculateEncodedSize.restype = C.c_uint64
     lib.AADHip_EncodePlanCreate.argtypes = [vp, C.POINTER(AADEncodeParameter), C.c_uint32, vp, C.POINTER(vp)]

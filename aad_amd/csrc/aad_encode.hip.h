@@ -242,7 +242,8 @@ struct EncodeArgs {
   const StreamDesc *streams;
   const int16_t *pcm;
   uint8_t *data;
-  LaneStateRecord *state; /* may be null */
+  const LaneStateRecord *state; /* carried state read at the start; may be null (fresh encoders) */
+  LaneStateRecord *state_out;   /* where the state is left at the end; may be null, may equal `state` */
   uint32_t num_streams;
   uint32_t channels;
   uint32_t block_size;
@@ -701,13 +702,13 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   }
 
-  if (a.state && writer) {
+  if (a.state_out && writer) {
     LaneStateRecord r;
     r.weight[0] = F.w0; r.weight[1] = F.w1; r.weight[2] = F.w2; r.weight[3] = F.w3;
     r.history[0] = F.h0; r.history[1] = F.h1; r.history[2] = F.h2; r.history[3] = F.h3;
     r.stepsize_index = F.idxb - kIdxBias;
     r.quantize_error = last_qd;
-    a.state[lane] = r;
+    a.state_out[lane] = r;
   }
 }
 

@@ -141,3 +141,9 @@ uint64_t AADFormat_EncodedSize(const struct AADHeaderInfo *h)
   if (tail != 0) size += AADFormat_BlockBytes(tail, h->num_channels, h->bits_per_sample);
   return size;
 }
+
+int AADFormat_DecodeWorkBounded(const struct AADHeaderInfo *h, uint32_t num_samples)
+{
+  const uint32_t per_block = num_samples < h->num_samples_per_block ? num_samples : h->num_samples_per_block;
+  return per_block < 0x80000000u;
+}

@@ -47,6 +47,14 @@ uint32_t AADFormat_BlockBytes(uint32_t n, uint32_t num_channels, uint32_t bits_p
 /* bytes of header + all blocks */
 uint64_t AADFormat_EncodedSize(const struct AADHeaderInfo *header);
 
+
+/* The device's per-block loop counters are 32-bit and one lane decodes a whole block: a header may
+ * claim any samples-per-block (nothing in reference src/aad_decoder.c:173-225 ties it to the block
+ * size), so a stream whose largest block would hold 2^31 samples per channel or more is refused
+ * (it could not be real data: a 65535-byte block holds at most 262 072 coded samples).
+ * Returns non-zero when min(num_samples, samples_per_block) is below that bound. */
+int AADFormat_DecodeWorkBounded(const struct AADHeaderInfo *header, uint32_t num_samples);
+
 #ifdef __cplusplus
 }
 #endif

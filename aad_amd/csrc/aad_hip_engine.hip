@@ -25,9 +25,11 @@ static_assert(sizeof(AADHipStreamDesc) == sizeof(aad::StreamDesc), "stream table
 static_assert(sizeof(AADHipLaneState) == sizeof(aad::LaneStateRecord), "lane state layout");
 static_assert(sizeof(AADHipErrorStats) == sizeof(aad::ErrorStatsRecord), "error stats layout");
 
-/* grow-only pinned-host + device buffer pair used by the host-memory convenience calls: all
- * streams of a batch are packed into ONE pinned block and cross PCIe in ONE copy each way
- * (a copy per stream from pageable memory cost ~10 us apiece: 20 ms for the 1000-stream batch) */
+/* grow-only pinned-host + device buffer pair used by the host-memory calls.  Everything a run
+ * needs (stream table, block prefix, carried state, payload) is laid out in ONE pinned block and
+ * crosses PCIe in ONE copy each way: a copy per stream from pageable memory cost ~10 us apiece
+ * (20 ms for a 1000-stream batch), and per-call hipMalloc / table upload / extra synchronisations
+ * cost more than the kernels themselves (round 1: 2.9 ms per call for a 0.075 ms kernel). */
 struct Staging {
   void *host = nullptr, *dev = nullptr;
   size_t cap = 0;
@@ -38,18 +40,27 @@ struct AADHipContext {
   hipStream_t stream;
   bool owns_stream;
   char last_error[256];
-  Staging pcm, data, pcm_out;
+  /* double-buffered so that a big batch can be cut into chunks: while chunk k is on the device the
+   * host fills chunk k+1's input block and drains chunk k-1's output block */
+  Staging in[2], out[2];
+  hipEvent_t chunk_done[2];
+  bool have_events;
+  /* device-only scratch of the reconstruction modes (the .aad images never leave HBM) */
+  void *d_scratch;
+  size_t scratch_capacity;
   /* scratch of the split decoder (dequantised differences), grow-only and shared by every decode
    * plan of the context: their runs are ordered by the context's one stream */
   int32_t *d_residual;
   uint64_t residual_capacity;
+  /* AADHip_ContextSetOption; the defaults come from the environment ONCE, at creation */
+  int32_t lane_mapping; /* enum AADHipLaneMapping */
+  int32_t trial_lanes;  /* enum AADHipTrialLanes */
 };
 
 struct AADHipEncodePlan {
   AADHipContext *ctx;
   aad::EncodeArgs args;
   aad::StreamDesc *d_streams;
-  uint64_t mean_blocks_per_stream;
 };
 
 struct AADHipDecodePlan {
@@ -154,14 +165,14 @@ unsigned pick_workgroup(uint64_t threads) { return threads <= 64ull * 1024ull ? 
 
 /* Lane mapping: "quad" (four lanes per recurrence, fewer instructions per sample) while the
  * batch cannot fill the chip anyway, "dense" (one lane per recurrence, fewest total
- * instructions) beyond that.  The crossover is two quad-waves per SIMD.  AAD_HIP_MAPPING=dense|quad
- * overrides the choice (the parity tests run both). */
-bool pick_quad(uint64_t recurrences, uint32_t channels)
+ * instructions) beyond that.  The crossover is two quad-waves per SIMD.  A context option
+ * (AADHip_ContextSetOption, default from AAD_HIP_MAPPING at context creation) forces one; the
+ * parity tests run all of them. */
+bool pick_quad(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels)
 {
   if (channels > 2) return false;
-  const char *e = getenv("AAD_HIP_MAPPING");
-  if (e != nullptr && strcmp(e, "dense") == 0) return false;
-  if (e != nullptr && (strcmp(e, "quad") == 0 || strcmp(e, "quad-fused") == 0)) return true;
+  if (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_DENSE) return false;
+  if (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_QUAD || ctx->lane_mapping == AAD_HIP_LANE_MAPPING_QUAD_FUSED) return true;
   return recurrences * 4 <= 2ull * 1024ull * 64ull;
 }
 
@@ -180,20 +191,20 @@ void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipSt
 
 /* On the quad mapping the trial search's probe strand gets lanes of its own ("dual"): one pass of
  * latency less per block with a predecessor, nothing lost otherwise (tools/trial_probe.py).
- * AAD_HIP_TRIAL_LANES=single keeps both strands on the same lanes (the parity tests run both). */
-bool pick_dual(const aad::EncodeArgs &a, bool quad, uint64_t /*mean_blocks_per_stream*/)
+ * AAD_HIP_OPTION_TRIAL_LANES = single keeps both strands on the same lanes (the parity tests run both). */
+bool pick_dual(const AADHipContext *ctx, const aad::EncodeArgs &a, bool quad)
 {
   if (!quad || a.trials == 0) return false;
-  const char *e = getenv("AAD_HIP_TRIAL_LANES");
-  return !(e != nullptr && strcmp(e, "single") == 0);
+  return ctx->trial_lanes != AAD_HIP_TRIAL_LANES_SINGLE;
 }
 
 template <int BITS>
-void launch_encode(const aad::EncodeArgs &a, hipStream_t stream, uint64_t mean_blocks_per_stream)
+void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
 {
+  const hipStream_t stream = ctx->stream;
   const uint64_t lanes = (uint64_t)a.num_streams * a.channels;
-  const bool quad = pick_quad(lanes, a.channels);
-  const bool dual = pick_dual(a, quad, mean_blocks_per_stream);
+  const bool quad = pick_quad(ctx, lanes, a.channels);
+  const bool dual = pick_dual(ctx, a, quad);
   const uint64_t threads = quad ? lanes * (dual ? 8 : 4) : lanes;
   const unsigned wg = pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
@@ -230,22 +241,24 @@ constexpr uint64_t kMaxResidualBytes = 1ull << 30;
  * fused quad kernel from there to ~20 k, the dense mapping beyond.  AAD_HIP_MAPPING forces one. */
 enum class DecodeMapping { Dense, QuadFused, QuadSplit };
 
-DecodeMapping pick_decode_mapping(uint64_t recurrences, uint32_t channels)
+DecodeMapping pick_decode_mapping(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels)
 {
   if (channels > 2) return DecodeMapping::Dense;
-  const char *e = getenv("AAD_HIP_MAPPING");
-  if (e != nullptr && strcmp(e, "dense") == 0) return DecodeMapping::Dense;
-  if (e != nullptr && strcmp(e, "quad-fused") == 0) return DecodeMapping::QuadFused;
-  if (e != nullptr && strcmp(e, "quad") == 0) return DecodeMapping::QuadSplit;
+  switch (ctx->lane_mapping) {
+    case AAD_HIP_LANE_MAPPING_DENSE: return DecodeMapping::Dense;
+    case AAD_HIP_LANE_MAPPING_QUAD_FUSED: return DecodeMapping::QuadFused;
+    case AAD_HIP_LANE_MAPPING_QUAD: return DecodeMapping::QuadSplit;
+    default: break;
+  }
   if (recurrences <= 8192) return DecodeMapping::QuadSplit;
   if (recurrences <= 20480) return DecodeMapping::QuadFused;
   return DecodeMapping::Dense;
 }
 
-bool want_split_decode(const aad::DecodeArgs &a, uint64_t *bytes, uint32_t *stride)
+bool want_split_decode(const AADHipContext *ctx, const aad::DecodeArgs &a, uint64_t *bytes, uint32_t *stride)
 {
   const uint64_t recurrences = a.total_blocks * a.channels;
-  if (pick_decode_mapping(recurrences, a.channels) != DecodeMapping::QuadSplit) return false;
+  if (pick_decode_mapping(ctx, recurrences, a.channels) != DecodeMapping::QuadSplit) return false;
   /* 64-bit: samples_per_block comes straight from a file header and may be anything */
   const uint64_t coded = a.samples_per_block > 4 ? (uint64_t)a.samples_per_block - 4 : 0;
   const uint64_t row = (coded + 15u) / 16u * 16u + 16u;
@@ -256,16 +269,153 @@ bool want_split_decode(const aad::DecodeArgs &a, uint64_t *bytes, uint32_t *stri
 }
 
 template <int BITS>
-void launch_decode(const aad::DecodeArgs &a, hipStream_t stream, int32_t *residual, uint32_t residual_stride)
+void launch_decode(const AADHipContext *ctx, const aad::DecodeArgs &a, int32_t *residual, uint32_t residual_stride)
 {
+  const hipStream_t stream = ctx->stream;
   if (residual != nullptr && aad::launch_decode_split(a, residual, residual_stride, stream)) return;
   const uint64_t lanes = a.total_blocks * a.channels;
-  const bool quad = pick_decode_mapping(lanes, a.channels) != DecodeMapping::Dense;
+  const bool quad = pick_decode_mapping(ctx, lanes, a.channels) != DecodeMapping::Dense;
   const uint64_t threads = quad ? lanes * 4 : lanes;
   const unsigned wg = pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
   if (quad) launch_decode_mapped<BITS, true>(a, grid, block, stream);
   else launch_decode_mapped<BITS, false>(a, grid, block, stream);
+}
+
+} /* namespace */
+
+/* ---- plan construction without any device work ------------------------------------------------
+ * Validation + launch arguments.  AADHip_*PlanCreate adds the table upload; the host-memory
+ * calls put the tables into the block that carries the payload instead. */
+namespace {
+
+AADApiResult encode_plan_init(const struct AADEncodeParameter *parameter, uint32_t num_streams,
+                              const struct AADHipStreamDesc *streams, aad::EncodeArgs *args)
+{
+  AADHeaderInfo h;
+  if (AADFormat_ParameterToHeader(parameter, 1, AAD_HIP_MAX_NUM_CHANNELS, &h) != AAD_APIRESULT_OK)
+    return AAD_APIRESULT_INVALID_FORMAT;
+  /* what AADEncoder_EncodeHeader would reject (bits == 1, zero rate, M/S on mono, ...) */
+  if (!AADFormat_HeaderFieldsValid(&h, AAD_HIP_MAX_NUM_CHANNELS)) return AAD_APIRESULT_INVALID_FORMAT;
+  if (h.ch_process_method == AAD_CH_PROCESS_METHOD_MS && h.num_channels != 2) return AAD_APIRESULT_INVALID_FORMAT;
+  for (uint32_t i = 0; i < num_streams; i++) {
+    if (streams[i].num_samples == 0) return AAD_APIRESULT_INVALID_FORMAT; /* src/aad_encoder.c:157-159 */
+    h.num_samples = streams[i].num_samples;
+    if (streams[i].data_size < AADFormat_EncodedSize(&h)) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
+  }
+  memset(args, 0, sizeof(*args));
+  args->num_streams = num_streams;
+  args->channels = h.num_channels;
+  args->block_size = h.block_size;
+  args->samples_per_block = h.num_samples_per_block;
+  args->mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
+  args->trials = parameter->num_encode_trials;
+  args->uni = detect_uniform(num_streams, streams);
+  h.num_samples = 0;
+  AADFormat_PutHeader(&h, args->header_template);
+  args->bits = h.bits_per_sample;
+  return AAD_APIRESULT_OK;
+}
+
+/* prefix: num_streams + 1 entries, the exclusive prefix sum of blocks per stream */
+AADApiResult decode_plan_init(const struct AADHeaderInfo *format, int32_t has_file_header, uint32_t num_streams,
+                              const struct AADHipStreamDesc *streams, uint64_t *prefix, aad::DecodeArgs *args)
+{
+  AADHeaderInfo h = *format;
+  h.num_samples = 1; /* per-stream counts come from the table */
+  if (!AADFormat_HeaderAcceptedByDecoder(&h, AAD_HIP_MAX_NUM_CHANNELS)) return AAD_APIRESULT_INVALID_FORMAT;
+  if (h.ch_process_method == AAD_CH_PROCESS_METHOD_MS && h.num_channels != 2) return AAD_APIRESULT_INVALID_FORMAT;
+  uint64_t blocks = 0;
+  const uint32_t head = has_file_header ? AAD_HEADER_SIZE : 0;
+  for (uint32_t i = 0; i < num_streams; i++) {
+    prefix[i] = blocks;
+    /* per-block loop counters on the device are 32-bit: a header that claims a block of 2^31
+     * samples and more (nothing in the reference's checks forbids it) is refused here */
+    if (!AADFormat_DecodeWorkBounded(&h, streams[i].num_samples)) return AAD_APIRESULT_INVALID_FORMAT;
+    /* the reference walks blocks while samples remain AND bytes remain (src/aad_decoder.c:514) */
+    const uint64_t by_samples = ((uint64_t)streams[i].num_samples + h.num_samples_per_block - 1) / h.num_samples_per_block;
+    const uint64_t payload = streams[i].data_size > head ? streams[i].data_size - head : 0;
+    const uint64_t by_bytes = (payload + h.block_size - 1) / h.block_size;
+    const uint64_t nblk = by_samples < by_bytes ? by_samples : by_bytes;
+    /* a present block shorter than its header is the reference's INSUFFICIENT_DATA (src/aad_decoder.c:347-349) */
+    if (nblk > 0) {
+      const uint64_t last_bytes = payload - (nblk - 1) * h.block_size;
+      if (last_bytes < (uint64_t)AAD_BLOCK_HEADER_BYTES_PER_CH * h.num_channels) return AAD_APIRESULT_INSUFFICIENT_DATA;
+    }
+    blocks += nblk;
+  }
+  prefix[num_streams] = blocks;
+  memset(args, 0, sizeof(*args));
+  args->total_blocks = blocks;
+  args->num_streams = num_streams;
+  args->channels = h.num_channels;
+  args->block_size = h.block_size;
+  args->samples_per_block = h.num_samples_per_block;
+  args->header_bytes = head;
+  args->uni = detect_uniform(num_streams, streams);
+  if (args->uni.enabled) {
+    args->uni.blocks_per_stream = (uint32_t)(num_streams ? prefix[1] - prefix[0] : 0);
+    if (args->uni.blocks_per_stream == 0 || blocks >= 0xFFFFFFFFull) args->uni.enabled = 0;
+  }
+  args->mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
+  args->bits = h.bits_per_sample;
+  return AAD_APIRESULT_OK;
+}
+
+/* launch with fully populated arguments (device pointers set) on the context's stream */
+AADApiResult run_encode(AADHipContext *ctx, const aad::EncodeArgs &a)
+{
+  if (a.num_streams == 0) return AAD_APIRESULT_OK;
+  switch (a.bits) {
+    case 4: launch_encode<4>(ctx, a); break;
+    case 3: launch_encode<3>(ctx, a); break;
+    case 2: launch_encode<2>(ctx, a); break;
+    default: return AAD_APIRESULT_INVALID_FORMAT;
+  }
+  return hip_ok(ctx, hipGetLastError(), "encode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+}
+
+AADApiResult run_decode(AADHipContext *ctx, const aad::DecodeArgs &a)
+{
+  if (a.total_blocks == 0) return AAD_APIRESULT_OK;
+  uint64_t residual_bytes = 0;
+  uint32_t residual_stride = 0;
+  int32_t *residual = nullptr;
+  const bool split = want_split_decode(ctx, a, &residual_bytes, &residual_stride);
+  const bool split_in_lds = split && aad::decode_split_fits_lds(a);
+  if (split && !split_in_lds) {
+    if (ctx->residual_capacity < residual_bytes) { /* first such decode of this size on the context */
+      if (ctx->d_residual) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->d_residual);
+        ctx->d_residual = nullptr;
+        ctx->residual_capacity = 0;
+      }
+      if (!hip_ok(ctx, hipMalloc((void **)&ctx->d_residual, residual_bytes), "hipMalloc residual scratch")) return AAD_APIRESULT_NG;
+      ctx->residual_capacity = residual_bytes;
+    }
+    residual = ctx->d_residual;
+  }
+  if (split_in_lds) {
+    if (!aad::launch_decode_split(a, nullptr, 0, ctx->stream)) return AAD_APIRESULT_INVALID_FORMAT;
+    return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+  }
+  switch (a.bits) {
+    case 4: launch_decode<4>(ctx, a, residual, residual_stride); break;
+    case 3: launch_decode<3>(ctx, a, residual, residual_stride); break;
+    case 2: launch_decode<2>(ctx, a, residual, residual_stride); break;
+    default: return AAD_APIRESULT_INVALID_FORMAT;
+  }
+  return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+}
+
+int32_t option_from_env(const char *name, const char *const *words, int32_t count)
+{
+  const char *e = getenv(name);
+  if (e == nullptr) return 0;
+  for (int32_t i = 0; i < count; i++)
+    if (strcmp(e, words[i]) == 0) return i;
+  return 0;
 }
 
 } /* namespace */
@@ -293,8 +443,14 @@ AADApiResult AADHip_ContextCreate(int32_t device_index, void *hip_stream, struct
   ctx->stream = static_cast<hipStream_t>(hip_stream);
   ctx->owns_stream = false;
   ctx->last_error[0] = 0;
+  ctx->have_events = false;
+  ctx->d_scratch = nullptr;
+  ctx->scratch_capacity = 0;
   ctx->d_residual = nullptr;
   ctx->residual_capacity = 0;
+  /* the environment is consulted here (and when the legacy API takes a parked context back into
+   * use), never on a launch path */
+  AADHipInternal_ContextOptionsFromEnvironment(ctx);
   DeviceGuard guard(ctx);
   if (!guard.ok) {
     delete ctx;
@@ -318,9 +474,12 @@ void AADHip_ContextDestroy(struct AADHipContext *ctx)
     DeviceGuard guard(ctx);
     if (guard.ok) {
       (void)hipStreamSynchronize(ctx->stream);
-      staging_release(ctx->pcm);
-      staging_release(ctx->data);
-      staging_release(ctx->pcm_out);
+      for (int b = 0; b < 2; b++) {
+        staging_release(ctx->in[b]);
+        staging_release(ctx->out[b]);
+        if (ctx->have_events) (void)hipEventDestroy(ctx->chunk_done[b]);
+      }
+      if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
       if (ctx->d_residual) (void)hipFree(ctx->d_residual);
       if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     }
@@ -337,6 +496,33 @@ AADApiResult AADHip_ContextSynchronize(struct AADHipContext *ctx)
 }
 
 const char *AADHip_ContextLastError(const struct AADHipContext *ctx) { return ctx ? ctx->last_error : ""; }
+
+void AADHipInternal_ContextOptionsFromEnvironment(struct AADHipContext *ctx)
+{
+  static const char *const kMappings[] = {"auto", "dense", "quad", "quad-fused"};
+  static const char *const kTrialLanes[] = {"dual", "single"};
+  ctx->lane_mapping = option_from_env("AAD_HIP_MAPPING", kMappings, 4);
+  ctx->trial_lanes = option_from_env("AAD_HIP_TRIAL_LANES", kTrialLanes, 2);
+}
+
+int32_t AADHipInternal_ContextDevice(const struct AADHipContext *ctx) { return ctx->device; }
+
+AADApiResult AADHip_ContextSetOption(struct AADHipContext *ctx, int32_t option, int32_t value)
+{
+  if (ctx == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
+  switch (option) {
+    case AAD_HIP_OPTION_LANE_MAPPING:
+      if (value < AAD_HIP_LANE_MAPPING_AUTO || value > AAD_HIP_LANE_MAPPING_QUAD_FUSED) return AAD_APIRESULT_INVALID_ARGUMENT;
+      ctx->lane_mapping = value;
+      return AAD_APIRESULT_OK;
+    case AAD_HIP_OPTION_TRIAL_LANES:
+      if (value != AAD_HIP_TRIAL_LANES_DUAL && value != AAD_HIP_TRIAL_LANES_SINGLE) return AAD_APIRESULT_INVALID_ARGUMENT;
+      ctx->trial_lanes = value;
+      return AAD_APIRESULT_OK;
+    default:
+      return AAD_APIRESULT_INVALID_ARGUMENT;
+  }
+}
 
 uint64_t AADHip_CalculateEncodedSize(const struct AADEncodeParameter *parameter, uint32_t num_samples)
 {
@@ -356,43 +542,21 @@ AADApiResult AADHip_EncodePlanCreate(struct AADHipContext *ctx, const struct AAD
   if (ctx == nullptr || parameter == nullptr || plan == nullptr || (num_streams != 0 && streams == nullptr))
     return AAD_APIRESULT_INVALID_ARGUMENT;
   *plan = nullptr;
-  AADHeaderInfo h;
-  if (AADFormat_ParameterToHeader(parameter, 1, AAD_HIP_MAX_NUM_CHANNELS, &h) != AAD_APIRESULT_OK)
-    return AAD_APIRESULT_INVALID_FORMAT;
-  /* what AADEncoder_EncodeHeader would reject (bits == 1, zero rate, M/S on mono, ...) */
-  if (!AADFormat_HeaderFieldsValid(&h, AAD_HIP_MAX_NUM_CHANNELS)) return AAD_APIRESULT_INVALID_FORMAT;
-  if (h.ch_process_method == AAD_CH_PROCESS_METHOD_MS && h.num_channels != 2) return AAD_APIRESULT_INVALID_FORMAT;
-  uint64_t total_blocks = 0;
-  for (uint32_t i = 0; i < num_streams; i++) {
-    if (streams[i].num_samples == 0) return AAD_APIRESULT_INVALID_FORMAT; /* src/aad_encoder.c:157-159 */
-    h.num_samples = streams[i].num_samples;
-    if (streams[i].data_size < AADFormat_EncodedSize(&h)) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
-    total_blocks += ((uint64_t)streams[i].num_samples + h.num_samples_per_block - 1) / h.num_samples_per_block;
-  }
-
+  aad::EncodeArgs args;
+  const AADApiResult rc = encode_plan_init(parameter, num_streams, streams, &args);
+  if (rc != AAD_APIRESULT_OK) return rc;
   AADHipEncodePlan *p = new (std::nothrow) AADHipEncodePlan();
   if (p == nullptr) return AAD_APIRESULT_NG;
   p->ctx = ctx;
   p->d_streams = nullptr;
-  p->mean_blocks_per_stream = num_streams ? total_blocks / num_streams : 0;
   DeviceGuard guard(ctx);
   if (!guard.ok || !upload(ctx, &p->d_streams, reinterpret_cast<const aad::StreamDesc *>(streams), num_streams)) {
     if (p->d_streams) (void)hipFree(p->d_streams);
     delete p;
     return AAD_APIRESULT_NG;
   }
-  memset(&p->args, 0, sizeof(p->args));
+  p->args = args;
   p->args.streams = p->d_streams;
-  p->args.num_streams = num_streams;
-  p->args.channels = h.num_channels;
-  p->args.block_size = h.block_size;
-  p->args.samples_per_block = h.num_samples_per_block;
-  p->args.mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
-  p->args.trials = parameter->num_encode_trials;
-  p->args.uni = detect_uniform(num_streams, streams);
-  h.num_samples = 0;
-  AADFormat_PutHeader(&h, p->args.header_template);
-  p->args.bits = h.bits_per_sample;
   *plan = p;
   return AAD_APIRESULT_OK;
 }
@@ -419,14 +583,9 @@ AADApiResult AADHip_EncodePlanRun(struct AADHipEncodePlan *plan, const int16_t *
   aad::EncodeArgs a = plan->args;
   a.pcm = device_pcm;
   a.data = device_data;
-  a.state = reinterpret_cast<aad::LaneStateRecord *>(device_state);
-  switch (a.bits) {
-    case 4: launch_encode<4>(a, ctx->stream, plan->mean_blocks_per_stream); break;
-    case 3: launch_encode<3>(a, ctx->stream, plan->mean_blocks_per_stream); break;
-    case 2: launch_encode<2>(a, ctx->stream, plan->mean_blocks_per_stream); break;
-    default: return AAD_APIRESULT_INVALID_FORMAT;
-  }
-  return hip_ok(ctx, hipGetLastError(), "encode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+  a.state = reinterpret_cast<const aad::LaneStateRecord *>(device_state);
+  a.state_out = reinterpret_cast<aad::LaneStateRecord *>(device_state);
+  return run_encode(ctx, a);
 }
 
 /* ------------------------------------------------------------------------------- decode -- */
@@ -438,29 +597,10 @@ AADApiResult AADHip_DecodePlanCreate(struct AADHipContext *ctx, const struct AAD
   if (ctx == nullptr || format == nullptr || plan == nullptr || (num_streams != 0 && streams == nullptr))
     return AAD_APIRESULT_INVALID_ARGUMENT;
   *plan = nullptr;
-  AADHeaderInfo h = *format;
-  h.num_samples = 1; /* per-stream counts come from the table */
-  if (!AADFormat_HeaderAcceptedByDecoder(&h, AAD_HIP_MAX_NUM_CHANNELS)) return AAD_APIRESULT_INVALID_FORMAT;
-  if (h.ch_process_method == AAD_CH_PROCESS_METHOD_MS && h.num_channels != 2) return AAD_APIRESULT_INVALID_FORMAT;
-
   std::vector<uint64_t> prefix((size_t)num_streams + 1);
-  uint64_t blocks = 0;
-  const uint32_t head = has_file_header ? AAD_HEADER_SIZE : 0;
-  for (uint32_t i = 0; i < num_streams; i++) {
-    prefix[i] = blocks;
-    /* the reference walks blocks while samples remain AND bytes remain (src/aad_decoder.c:514) */
-    const uint64_t by_samples = ((uint64_t)streams[i].num_samples + h.num_samples_per_block - 1) / h.num_samples_per_block;
-    const uint64_t payload = streams[i].data_size > head ? streams[i].data_size - head : 0;
-    const uint64_t by_bytes = (payload + h.block_size - 1) / h.block_size;
-    const uint64_t nblk = by_samples < by_bytes ? by_samples : by_bytes;
-    /* a present block shorter than its header is the reference's INSUFFICIENT_DATA (src/aad_decoder.c:347-349) */
-    if (nblk > 0) {
-      const uint64_t last_bytes = payload - (nblk - 1) * h.block_size;
-      if (last_bytes < (uint64_t)AAD_BLOCK_HEADER_BYTES_PER_CH * h.num_channels) return AAD_APIRESULT_INSUFFICIENT_DATA;
-    }
-    blocks += nblk;
-  }
-  prefix[num_streams] = blocks;
+  aad::DecodeArgs args;
+  const AADApiResult rc = decode_plan_init(format, has_file_header, num_streams, streams, prefix.data(), &args);
+  if (rc != AAD_APIRESULT_OK) return rc;
 
   AADHipDecodePlan *p = new (std::nothrow) AADHipDecodePlan();
   if (p == nullptr) return AAD_APIRESULT_NG;
@@ -475,22 +615,9 @@ AADApiResult AADHip_DecodePlanCreate(struct AADHipContext *ctx, const struct AAD
     delete p;
     return AAD_APIRESULT_NG;
   }
-  memset(&p->args, 0, sizeof(p->args));
+  p->args = args;
   p->args.streams = p->d_streams;
   p->args.block_prefix = p->d_prefix;
-  p->args.total_blocks = blocks;
-  p->args.num_streams = num_streams;
-  p->args.channels = h.num_channels;
-  p->args.block_size = h.block_size;
-  p->args.samples_per_block = h.num_samples_per_block;
-  p->args.header_bytes = head;
-  p->args.uni = detect_uniform(num_streams, streams);
-  if (p->args.uni.enabled) {
-    p->args.uni.blocks_per_stream = (uint32_t)(prefix.size() > 1 ? prefix[1] - prefix[0] : 0);
-    if (p->args.uni.blocks_per_stream == 0 || blocks >= 0xFFFFFFFFull) p->args.uni.enabled = 0;
-  }
-  p->args.mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
-  p->args.bits = h.bits_per_sample;
   *plan = p;
   return AAD_APIRESULT_OK;
 }
@@ -517,49 +644,259 @@ AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *
   aad::DecodeArgs a = plan->args;
   a.data = device_data;
   a.pcm = device_pcm;
-  uint64_t residual_bytes = 0;
-  uint32_t residual_stride = 0;
-  int32_t *residual = nullptr;
-  bool split = want_split_decode(a, &residual_bytes, &residual_stride);
-  const bool split_in_lds = split && aad::decode_split_fits_lds(a);
-  if (split && !split_in_lds) {
-    if (ctx->residual_capacity < residual_bytes) { /* first such decode of this size on the context */
-      if (ctx->d_residual) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(ctx->d_residual);
-        ctx->d_residual = nullptr;
-        ctx->residual_capacity = 0;
-      }
-      if (!hip_ok(ctx, hipMalloc((void **)&ctx->d_residual, residual_bytes), "hipMalloc residual scratch")) return AAD_APIRESULT_NG;
-      ctx->residual_capacity = residual_bytes;
-    }
-    residual = ctx->d_residual;
-  }
-  if (split_in_lds) {
-    if (!aad::launch_decode_split(a, nullptr, 0, ctx->stream)) return AAD_APIRESULT_INVALID_FORMAT;
-    return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
-  }
-  switch (a.bits) {
-    case 4: launch_decode<4>(a, ctx->stream, residual, residual_stride); break;
-    case 3: launch_decode<3>(a, ctx->stream, residual, residual_stride); break;
-    case 2: launch_decode<2>(a, ctx->stream, residual, residual_stride); break;
-    default: return AAD_APIRESULT_INVALID_FORMAT;
-  }
-  return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+  return run_decode(ctx, a);
 }
 
-/* --------------------------------------------------------------- host-memory convenience -- */
+} /* extern "C" */
 
+/* --------------------------------------------------------------- host-memory calls ----------
+ *
+ * Call pattern served: the reference CLI's (src/main.c:182-198 encode, :91-106 decode) - host
+ * buffers in, host buffers out, synchronous - for one stream (legacy API) or many (AADHip_*Batch).
+ *
+ * One chunk of streams = one pinned input block {stream table, [block prefix], [state], payload}
+ * -> ONE H2D copy -> kernel -> ONE D2H copy of the output block {payload, [state]}.  No hipMalloc,
+ * no plan object, no synchronisation besides the wait for the chunk's last copy.  Batches above
+ * kChunkBudget bytes are cut into chunks that alternate between two block pairs: the host fills
+ * chunk k+1 and drains chunk k-1 while chunk k is on the device (the staging memcpys are the
+ * slowest stage of this path - one core moves ~10 GB/s, PCIe ~50 GB/s, the kernels more).
+ */
 namespace {
-struct DeviceBuffer {
-  void *p = nullptr;
-  ~DeviceBuffer()
+
+uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+constexpr uint64_t kChunkBudget = 8ull << 20; /* payload bytes (in + out) per chunk of a cut batch */
+constexpr uint64_t kCutAbove = 2 * kChunkBudget;
+
+bool ensure_events(AADHipContext *ctx)
+{
+  if (ctx->have_events) return true;
+  if (!hip_ok(ctx, hipEventCreateWithFlags(&ctx->chunk_done[0], hipEventDisableTiming), "hipEventCreate")) return false;
+  if (!hip_ok(ctx, hipEventCreateWithFlags(&ctx->chunk_done[1], hipEventDisableTiming), "hipEventCreate")) {
+    (void)hipEventDestroy(ctx->chunk_done[0]);
+    return false;
+  }
+  ctx->have_events = true;
+  return true;
+}
+
+/* [first, last) stream ranges whose payload stays within the budget (at least one stream each) */
+struct ChunkCutter {
+  uint64_t budget;
+  uint32_t n, pos = 0;
+  ChunkCutter(uint64_t total_bytes, uint32_t num_streams) : budget(total_bytes > kCutAbove ? kChunkBudget : ~0ull), n(num_streams) {}
+  template <class Cost>
+  bool next(Cost cost, uint32_t *first, uint32_t *last)
   {
-    if (p) (void)hipFree(p);
+    if (pos >= n) return false;
+    uint64_t sum = 0;
+    *first = pos;
+    do sum += cost(pos++); while (pos < n && sum + cost(pos) <= budget);
+    *last = pos;
+    return true;
   }
 };
-uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+/* one chunk in flight on buffer pair b */
+struct Flight {
+  uint32_t first = 0, last = 0;
+  bool active = false;
+};
+
+/*
+ * Encode num_streams host streams.  fill(i, dst) writes stream i's interleaved int16 frames,
+ * drain(i, src, size) receives its .aad image.  `state` as in AADHip_EncodeBatch.
+ */
+template <class Fill, class Drain>
+AADApiResult encode_host(AADHipContext *ctx, const struct AADEncodeParameter *parameter, uint32_t num_streams,
+                         const uint32_t *num_samples, const uint64_t *data_capacity, uint64_t *output_size,
+                         struct AADHipLaneState *state, Fill fill, Drain drain)
+{
+  const uint32_t ch = parameter->num_channels;
+  std::vector<uint64_t> sizes(num_streams);
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < num_streams; i++) {
+    sizes[i] = AADHip_CalculateEncodedSize(parameter, num_samples[i]);
+    if (sizes[i] == 0) return AAD_APIRESULT_INVALID_FORMAT;
+    if (data_capacity[i] < sizes[i]) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
+    total += (uint64_t)num_samples[i] * ch * sizeof(int16_t) + sizes[i];
+  }
+  DeviceGuard guard(ctx);
+  if (!guard.ok || !ensure_events(ctx)) return AAD_APIRESULT_NG;
+
+  auto cost = [&](uint32_t i) { return (uint64_t)num_samples[i] * ch * sizeof(int16_t) + sizes[i]; };
+  ChunkCutter cutter(total, num_streams);
+  Flight flight[2];
+  std::vector<AADHipStreamDesc> table;
+
+  /* wait for the chunk on pair b and hand its images (and states) to the caller */
+  auto finish = [&](int b) -> bool {
+    Flight &f = flight[b];
+    if (!f.active) return true;
+    f.active = false;
+    if (!hip_ok(ctx, hipEventSynchronize(ctx->chunk_done[b]), "hipEventSynchronize")) return false;
+    const uint8_t *out = static_cast<const uint8_t *>(ctx->out[b].host);
+    uint64_t off = 0;
+    for (uint32_t i = f.first; i < f.last; i++) {
+      drain(i, out + off, sizes[i]);
+      off += round_up(sizes[i], 16);
+    }
+    if (state) memcpy(state + (size_t)f.first * ch, out + off, sizeof(AADHipLaneState) * (size_t)(f.last - f.first) * ch);
+    return true;
+  };
+
+  AADApiResult rc = AAD_APIRESULT_OK;
+  uint32_t first, last;
+  for (int k = 0; rc == AAD_APIRESULT_OK && cutter.next(cost, &first, &last); k++) {
+    const int b = k & 1;
+    if (!finish(b)) { rc = AAD_APIRESULT_NG; break; }
+    const uint32_t n = last - first;
+    /* input block: table | state | pcm ; output block: images | state */
+    table.resize(n);
+    uint64_t pcm_elems = 0, data_bytes = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      table[i].pcm_offset = pcm_elems;
+      table[i].data_offset = data_bytes;
+      table[i].data_size = sizes[first + i];
+      table[i].num_samples = num_samples[first + i];
+      table[i].reserved = 0;
+      pcm_elems += round_up((uint64_t)num_samples[first + i] * ch, 8);
+      data_bytes += round_up(sizes[first + i], 16);
+    }
+    aad::EncodeArgs a;
+    rc = encode_plan_init(parameter, n, table.data(), &a);
+    if (rc != AAD_APIRESULT_OK) break;
+    const size_t table_bytes = round_up(sizeof(AADHipStreamDesc) * (size_t)n, 64);
+    const size_t state_bytes = state ? sizeof(AADHipLaneState) * (size_t)n * ch : 0;
+    const size_t pcm_off = table_bytes + round_up(state_bytes, 64);
+    const size_t in_bytes = pcm_off + pcm_elems * sizeof(int16_t);
+    const size_t out_bytes = data_bytes + state_bytes;
+    rc = AAD_APIRESULT_NG;
+    if (!staging_reserve(ctx, ctx->in[b], in_bytes + 64) || !staging_reserve(ctx, ctx->out[b], out_bytes + 64)) break;
+    uint8_t *hin = static_cast<uint8_t *>(ctx->in[b].host), *din = static_cast<uint8_t *>(ctx->in[b].dev);
+    uint8_t *dout = static_cast<uint8_t *>(ctx->out[b].dev);
+    memcpy(hin, table.data(), sizeof(AADHipStreamDesc) * (size_t)n);
+    if (state) memcpy(hin + table_bytes, state + (size_t)first * ch, state_bytes);
+    for (uint32_t i = 0; i < n; i++) fill(first + i, reinterpret_cast<int16_t *>(hin + pcm_off) + table[i].pcm_offset);
+    if (!hip_ok(ctx, hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D block")) break;
+    a.streams = reinterpret_cast<const aad::StreamDesc *>(din);
+    a.pcm = reinterpret_cast<const int16_t *>(din + pcm_off);
+    a.data = dout;
+    a.state = state ? reinterpret_cast<const aad::LaneStateRecord *>(din + table_bytes) : nullptr;
+    a.state_out = state ? reinterpret_cast<aad::LaneStateRecord *>(dout + data_bytes) : nullptr;
+    if (run_encode(ctx, a) != AAD_APIRESULT_OK) break;
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->out[b].host, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H block")) break;
+    if (!hip_ok(ctx, hipEventRecord(ctx->chunk_done[b], ctx->stream), "hipEventRecord")) break;
+    flight[b].first = first;
+    flight[b].last = last;
+    flight[b].active = true;
+    rc = AAD_APIRESULT_OK;
+  }
+  /* drain what is still in flight, oldest first (also on failure: the buffers must be idle on return) */
+  const int older = flight[0].active && flight[1].active && flight[1].first < flight[0].first ? 1 : 0;
+  if (!finish(older) && rc == AAD_APIRESULT_OK) rc = AAD_APIRESULT_NG;
+  if (!finish(older ^ 1) && rc == AAD_APIRESULT_OK) rc = AAD_APIRESULT_NG;
+  if (rc == AAD_APIRESULT_OK && output_size) memcpy(output_size, sizes.data(), sizeof(uint64_t) * num_streams);
+  return rc;
+}
+
+/*
+ * Decode num_streams host images of one format.  fill(i, dst) writes stream i's bytes
+ * (data_size[i] of them), drain(i, src, frames) receives its interleaved int16 frames.
+ */
+template <class Fill, class Drain>
+AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format, int32_t has_file_header,
+                         uint32_t num_streams, const uint64_t *data_size, const uint32_t *num_samples,
+                         uint32_t *decoded_frames, Fill fill, Drain drain)
+{
+  const uint32_t ch = format->num_channels, head = has_file_header ? AAD_HEADER_SIZE : 0;
+  if (ch == 0 || format->block_size == 0) return AAD_APIRESULT_INVALID_FORMAT;
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < num_streams; i++) total += data_size[i] + (uint64_t)num_samples[i] * ch * sizeof(int16_t);
+  DeviceGuard guard(ctx);
+  if (!guard.ok || !ensure_events(ctx)) return AAD_APIRESULT_NG;
+
+  auto cost = [&](uint32_t i) { return data_size[i] + (uint64_t)num_samples[i] * ch * sizeof(int16_t); };
+  /* frames the reference's block walk produces: it stops when the bytes run out (src/aad_decoder.c:514) */
+  auto frames_of = [&](uint32_t i) -> uint32_t {
+    const uint64_t payload = data_size[i] > head ? data_size[i] - head : 0;
+    const uint64_t frames = (payload + format->block_size - 1) / format->block_size * format->num_samples_per_block;
+    return frames < num_samples[i] ? (uint32_t)frames : num_samples[i];
+  };
+  ChunkCutter cutter(total, num_streams);
+  Flight flight[2];
+  std::vector<AADHipStreamDesc> table;
+  std::vector<uint64_t> prefix;
+
+  auto finish = [&](int b) -> bool {
+    Flight &f = flight[b];
+    if (!f.active) return true;
+    f.active = false;
+    if (!hip_ok(ctx, hipEventSynchronize(ctx->chunk_done[b]), "hipEventSynchronize")) return false;
+    const int16_t *out = static_cast<const int16_t *>(ctx->out[b].host);
+    uint64_t off = 0;
+    for (uint32_t i = f.first; i < f.last; i++) {
+      const uint32_t got = frames_of(i);
+      if (got) drain(i, out + off, got);
+      if (decoded_frames) decoded_frames[i] = got;
+      off += round_up((uint64_t)num_samples[i] * ch, 8);
+    }
+    return true;
+  };
+
+  AADApiResult rc = AAD_APIRESULT_OK;
+  uint32_t first, last;
+  for (int k = 0; rc == AAD_APIRESULT_OK && cutter.next(cost, &first, &last); k++) {
+    const int b = k & 1;
+    if (!finish(b)) { rc = AAD_APIRESULT_NG; break; }
+    const uint32_t n = last - first;
+    table.resize(n);
+    prefix.resize((size_t)n + 1);
+    uint64_t pcm_elems = 0, data_bytes = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      table[i].pcm_offset = pcm_elems;
+      table[i].data_offset = data_bytes;
+      table[i].data_size = data_size[first + i];
+      table[i].num_samples = num_samples[first + i];
+      table[i].reserved = 0;
+      pcm_elems += round_up((uint64_t)num_samples[first + i] * ch, 8);
+      data_bytes += round_up(data_size[first + i], 16);
+    }
+    aad::DecodeArgs a;
+    rc = decode_plan_init(format, has_file_header, n, table.data(), prefix.data(), &a);
+    if (rc != AAD_APIRESULT_OK) break;
+    const size_t table_bytes = round_up(sizeof(AADHipStreamDesc) * (size_t)n, 64);
+    const size_t prefix_bytes = round_up(sizeof(uint64_t) * ((size_t)n + 1), 64);
+    const size_t data_off = table_bytes + prefix_bytes;
+    const size_t in_bytes = data_off + data_bytes, out_bytes = pcm_elems * sizeof(int16_t);
+    rc = AAD_APIRESULT_NG;
+    if (!staging_reserve(ctx, ctx->in[b], in_bytes + 64) || !staging_reserve(ctx, ctx->out[b], out_bytes + 64)) break;
+    uint8_t *hin = static_cast<uint8_t *>(ctx->in[b].host), *din = static_cast<uint8_t *>(ctx->in[b].dev);
+    memcpy(hin, table.data(), sizeof(AADHipStreamDesc) * (size_t)n);
+    memcpy(hin + table_bytes, prefix.data(), sizeof(uint64_t) * ((size_t)n + 1));
+    for (uint32_t i = 0; i < n; i++) fill(first + i, hin + data_off + table[i].data_offset);
+    if (!hip_ok(ctx, hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D block")) break;
+    a.streams = reinterpret_cast<const aad::StreamDesc *>(din);
+    a.block_prefix = reinterpret_cast<const uint64_t *>(din + table_bytes);
+    a.data = din + data_off;
+    a.pcm = static_cast<int16_t *>(ctx->out[b].dev);
+    if (run_decode(ctx, a) != AAD_APIRESULT_OK) break;
+    if (out_bytes && !hip_ok(ctx, hipMemcpyAsync(ctx->out[b].host, ctx->out[b].dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H block")) break;
+    if (!hip_ok(ctx, hipEventRecord(ctx->chunk_done[b], ctx->stream), "hipEventRecord")) break;
+    flight[b].first = first;
+    flight[b].last = last;
+    flight[b].active = true;
+    rc = AAD_APIRESULT_OK;
+  }
+  const int older = flight[0].active && flight[1].active && flight[1].first < flight[0].first ? 1 : 0;
+  if (!finish(older) && rc == AAD_APIRESULT_OK) rc = AAD_APIRESULT_NG;
+  if (!finish(older ^ 1) && rc == AAD_APIRESULT_OK) rc = AAD_APIRESULT_NG;
+  return rc;
+}
+
 } /* namespace */
+
+extern "C" {
 
 AADApiResult AADHip_EncodeBatch(struct AADHipContext *ctx, const struct AADEncodeParameter *parameter,
                                 uint32_t num_streams, const int16_t *const *pcm, const uint32_t *num_samples,
@@ -570,51 +907,35 @@ AADApiResult AADHip_EncodeBatch(struct AADHipContext *ctx, const struct AADEncod
       data == nullptr || data_capacity == nullptr)))
     return AAD_APIRESULT_INVALID_ARGUMENT;
   if (num_streams == 0) return AAD_APIRESULT_OK;
-  std::vector<AADHipStreamDesc> table(num_streams);
-  std::vector<uint64_t> sizes(num_streams);
-  uint64_t pcm_elems = 0, data_bytes = 0;
-  const uint32_t ch = parameter->num_channels;
-  for (uint32_t i = 0; i < num_streams; i++) {
+  for (uint32_t i = 0; i < num_streams; i++)
     if (pcm[i] == nullptr || data[i] == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
-    sizes[i] = AADHip_CalculateEncodedSize(parameter, num_samples[i]);
-    if (sizes[i] == 0) return AAD_APIRESULT_INVALID_FORMAT;
-    if (data_capacity[i] < sizes[i]) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
-    table[i].pcm_offset = pcm_elems;
-    table[i].data_offset = data_bytes;
-    table[i].data_size = sizes[i];
-    table[i].num_samples = num_samples[i];
-    table[i].reserved = 0;
-    pcm_elems += round_up((uint64_t)num_samples[i] * ch, 8);
-    data_bytes += round_up(sizes[i], 16);
-  }
-  AADHipEncodePlan *plan = nullptr;
-  AADApiResult rc = AADHip_EncodePlanCreate(ctx, parameter, num_streams, table.data(), &plan);
-  if (rc != AAD_APIRESULT_OK) return rc;
-  DeviceGuard guard(ctx);
-  DeviceBuffer d_state;
-  const size_t state_bytes = sizeof(AADHipLaneState) * (size_t)num_streams * ch;
-  const size_t pcm_bytes = pcm_elems * sizeof(int16_t);
-  rc = AAD_APIRESULT_NG;
-  do {
-    if (!guard.ok) break;
-    if (!staging_reserve(ctx, ctx->pcm, pcm_bytes + 64) || !staging_reserve(ctx, ctx->data, data_bytes + 64)) break;
-    if (state) {
-      if (!hip_ok(ctx, hipMalloc(&d_state.p, state_bytes), "hipMalloc state")) break;
-      if (!hip_ok(ctx, hipMemcpyAsync(d_state.p, state, state_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D state")) break;
-    }
-    for (uint32_t i = 0; i < num_streams; i++)
-      memcpy((int16_t *)ctx->pcm.host + table[i].pcm_offset, pcm[i], (size_t)num_samples[i] * ch * sizeof(int16_t));
-    if (!hip_ok(ctx, hipMemcpyAsync(ctx->pcm.dev, ctx->pcm.host, pcm_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D pcm")) break;
-    if (AADHip_EncodePlanRun(plan, (const int16_t *)ctx->pcm.dev, (uint8_t *)ctx->data.dev, (AADHipLaneState *)d_state.p) != AAD_APIRESULT_OK) break;
-    if (!hip_ok(ctx, hipMemcpyAsync(ctx->data.host, ctx->data.dev, data_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H data")) break;
-    if (state && !hip_ok(ctx, hipMemcpyAsync(state, d_state.p, state_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H state")) break;
-    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
-    for (uint32_t i = 0; i < num_streams; i++) memcpy(data[i], (uint8_t *)ctx->data.host + table[i].data_offset, sizes[i]);
-    if (output_size) memcpy(output_size, sizes.data(), sizeof(uint64_t) * num_streams);
-    rc = AAD_APIRESULT_OK;
-  } while (0);
-  AADHip_EncodePlanDestroy(plan);
-  return rc;
+  const size_t frame_bytes = sizeof(int16_t) * parameter->num_channels;
+  return encode_host(ctx, parameter, num_streams, num_samples, data_capacity, output_size, state,
+                     [&](uint32_t i, int16_t *dst) { memcpy(dst, pcm[i], (size_t)num_samples[i] * frame_bytes); },
+                     [&](uint32_t i, const uint8_t *src, uint64_t size) { memcpy(data[i], src, size); });
+}
+
+/* AADEncoder_EncodeWhole's data path (src/aad_encoder.c:814-891): planar int32 rows in, one image
+ * out.  The planar -> interleaved int16 conversion writes straight into the pinned block; samples
+ * must already be in int16 range, which the reference only asserts (src/aad_encoder.c:612) -
+ * out-of-range input saturates. */
+AADApiResult AADHipInternal_EncodePlanar32(struct AADHipContext *ctx, const struct AADEncodeParameter *parameter,
+                                           const int32_t *const *input, uint32_t num_samples, uint8_t *data,
+                                           uint64_t data_capacity, uint64_t *output_size, struct AADHipLaneState *state)
+{
+  const uint32_t ch = parameter->num_channels;
+  return encode_host(ctx, parameter, 1, &num_samples, &data_capacity, output_size, state,
+                     [&](uint32_t, int16_t *dst) {
+                       for (uint32_t c = 0; c < ch; c++) {
+                         const int32_t *x = input[c];
+                         int16_t *d = dst + c;
+                         for (uint32_t s = 0; s < num_samples; s++, d += ch) {
+                           const int32_t v = x[s];
+                           *d = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+                         }
+                       }
+                     },
+                     [&](uint32_t, const uint8_t *src, uint64_t size) { memcpy(data, src, size); });
 }
 
 /* shared by AADHip_DecodeBatch (file images) and the legacy AADDecoder_DecodeBlock (bare block) */
@@ -623,45 +944,28 @@ AADApiResult AADHipInternal_DecodeHost(struct AADHipContext *ctx, const struct A
                                        const uint8_t *const *data, const uint64_t *data_size,
                                        const uint32_t *num_samples, int16_t *const *pcm, uint32_t *decoded_frames)
 {
-  std::vector<AADHipStreamDesc> table(num_streams);
-  std::vector<uint32_t> decoded(num_streams);
-  uint64_t pcm_elems = 0, data_bytes = 0;
-  const uint32_t ch = format->num_channels, head = has_file_header ? AAD_HEADER_SIZE : 0;
-  for (uint32_t i = 0; i < num_streams; i++) {
-    table[i].pcm_offset = pcm_elems;
-    table[i].data_offset = data_bytes;
-    table[i].data_size = data_size[i];
-    table[i].num_samples = num_samples[i];
-    table[i].reserved = 0;
-    pcm_elems += round_up((uint64_t)num_samples[i] * ch, 8);
-    data_bytes += round_up(data_size[i], 16);
-    /* frames the reference's block walk produces: it stops when the bytes run out (src/aad_decoder.c:514) */
-    const uint64_t payload = data_size[i] > head ? data_size[i] - head : 0;
-    const uint64_t frames = (payload + format->block_size - 1) / format->block_size * format->num_samples_per_block;
-    decoded[i] = frames < num_samples[i] ? (uint32_t)frames : num_samples[i];
-  }
-  AADHipDecodePlan *plan = nullptr;
-  AADApiResult rc = AADHip_DecodePlanCreate(ctx, format, has_file_header, num_streams, table.data(), &plan);
-  if (rc != AAD_APIRESULT_OK) return rc;
-  DeviceGuard guard(ctx);
-  const size_t pcm_bytes = pcm_elems * sizeof(int16_t);
-  rc = AAD_APIRESULT_NG;
-  do {
-    if (!guard.ok) break;
-    if (!staging_reserve(ctx, ctx->pcm, pcm_bytes + 64) || !staging_reserve(ctx, ctx->data, data_bytes + 64)) break;
-    for (uint32_t i = 0; i < num_streams; i++) memcpy((uint8_t *)ctx->data.host + table[i].data_offset, data[i], data_size[i]);
-    if (!hip_ok(ctx, hipMemcpyAsync(ctx->data.dev, ctx->data.host, data_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D data")) break;
-    if (AADHip_DecodePlanRun(plan, (const uint8_t *)ctx->data.dev, (int16_t *)ctx->pcm.dev) != AAD_APIRESULT_OK) break;
-    if (!hip_ok(ctx, hipMemcpyAsync(ctx->pcm.host, ctx->pcm.dev, pcm_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H pcm")) break;
-    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
-    for (uint32_t i = 0; i < num_streams; i++)
-      if (decoded[i])
-        memcpy(pcm[i], (int16_t *)ctx->pcm.host + table[i].pcm_offset, (size_t)decoded[i] * ch * sizeof(int16_t));
-    if (decoded_frames) memcpy(decoded_frames, decoded.data(), sizeof(uint32_t) * num_streams);
-    rc = AAD_APIRESULT_OK;
-  } while (0);
-  AADHip_DecodePlanDestroy(plan);
-  return rc;
+  const size_t frame_bytes = sizeof(int16_t) * format->num_channels;
+  return decode_host(ctx, format, has_file_header, num_streams, data_size, num_samples, decoded_frames,
+                     [&](uint32_t i, uint8_t *dst) { memcpy(dst, data[i], data_size[i]); },
+                     [&](uint32_t i, const int16_t *src, uint32_t frames) { memcpy(pcm[i], src, (size_t)frames * frame_bytes); });
+}
+
+/* AADDecoder_DecodeWhole / DecodeBlock's data path: one image (or bare block) in, planar int32
+ * rows out, widened straight from the pinned block (src/aad_decoder.c:478-538, :321-475) */
+AADApiResult AADHipInternal_DecodePlanar32(struct AADHipContext *ctx, const struct AADHeaderInfo *format,
+                                           int32_t has_file_header, const uint8_t *data, uint64_t data_size,
+                                           uint32_t want_frames, int32_t *const *buffer, uint32_t *decoded_frames)
+{
+  const uint32_t ch = format->num_channels;
+  return decode_host(ctx, format, has_file_header, 1, &data_size, &want_frames, decoded_frames,
+                     [&](uint32_t, uint8_t *dst) { memcpy(dst, data, data_size); },
+                     [&](uint32_t, const int16_t *src, uint32_t frames) {
+                       for (uint32_t c = 0; c < ch; c++) {
+                         int32_t *y = buffer[c];
+                         const int16_t *s = src + c;
+                         for (uint32_t k = 0; k < frames; k++, s += ch) y[k] = *s;
+                       }
+                     });
 }
 
 AADApiResult AADHip_DecodeBatch(struct AADHipContext *ctx, uint32_t num_streams, const uint8_t *const *data,
@@ -814,28 +1118,37 @@ AADApiResult AADHip_ReconstructBatch(struct AADHipContext *ctx, const struct AAD
   AADApiResult rc = AADHip_ReconstructPlanCreate(ctx, parameter, num_streams, table.data(), &plan);
   if (rc != AAD_APIRESULT_OK) return rc;
   DeviceGuard guard(ctx);
-  DeviceBuffer d_stats;
-  const size_t pcm_bytes = pcm_elems * sizeof(int16_t), stats_bytes = sizeof(AADHipErrorStats) * (size_t)num_streams;
+  /* input block: pcm ; output block: pcm out | stats ; the images stay in a device-only scratch */
+  const size_t pcm_bytes = pcm_elems * sizeof(int16_t), stats_bytes = stats ? sizeof(AADHipErrorStats) * (size_t)num_streams : 0;
+  const size_t stats_off = round_up(pcm_bytes, 64);
   rc = AAD_APIRESULT_NG;
   do {
     if (!guard.ok) break;
-    if (!staging_reserve(ctx, ctx->pcm, pcm_bytes + 64) || !staging_reserve(ctx, ctx->data, data_bytes + 64) ||
-        !staging_reserve(ctx, ctx->pcm_out, pcm_bytes + 64))
-      break;
-    if (stats && !hip_ok(ctx, hipMalloc(&d_stats.p, stats_bytes), "hipMalloc stats")) break;
+    if (!staging_reserve(ctx, ctx->in[0], pcm_bytes + 64) || !staging_reserve(ctx, ctx->out[0], stats_off + stats_bytes + 64)) break;
+    if (ctx->scratch_capacity < data_bytes + 64) {
+      if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+      ctx->d_scratch = nullptr;
+      ctx->scratch_capacity = 0;
+      if (!hip_ok(ctx, hipMalloc(&ctx->d_scratch, data_bytes + data_bytes / 4 + 4096), "hipMalloc image scratch")) break;
+      ctx->scratch_capacity = data_bytes + data_bytes / 4 + 4096;
+    }
+    int16_t *hin = static_cast<int16_t *>(ctx->in[0].host);
+    uint8_t *hout = static_cast<uint8_t *>(ctx->out[0].host), *dout = static_cast<uint8_t *>(ctx->out[0].dev);
     for (uint32_t i = 0; i < num_streams; i++)
-      memcpy((int16_t *)ctx->pcm.host + table[i].pcm_offset, pcm[i], (size_t)num_samples[i] * ch * sizeof(int16_t));
-    if (!hip_ok(ctx, hipMemcpyAsync(ctx->pcm.dev, ctx->pcm.host, pcm_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D pcm")) break;
-    rc = AADHip_ReconstructPlanRun(plan, (const int16_t *)ctx->pcm.dev, (uint8_t *)ctx->data.dev, (int16_t *)ctx->pcm_out.dev,
-                                   output_kind, (AADHipErrorStats *)d_stats.p);
+      memcpy(hin + table[i].pcm_offset, pcm[i], (size_t)num_samples[i] * ch * sizeof(int16_t));
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->in[0].dev, hin, pcm_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D pcm")) break;
+    rc = AADHip_ReconstructPlanRun(plan, (const int16_t *)ctx->in[0].dev, (uint8_t *)ctx->d_scratch, (int16_t *)dout,
+                                   output_kind, stats ? (AADHipErrorStats *)(dout + stats_off) : nullptr);
     if (rc != AAD_APIRESULT_OK) break;
     rc = AAD_APIRESULT_NG;
-    if (out_pcm && !hip_ok(ctx, hipMemcpyAsync(ctx->pcm_out.host, ctx->pcm_out.dev, pcm_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H pcm")) break;
-    if (stats && !hip_ok(ctx, hipMemcpyAsync(stats, d_stats.p, stats_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H stats")) break;
+    /* statistics only: nothing but 24 bytes per stream comes back */
+    const size_t back_off = out_pcm ? 0 : stats_off, back_bytes = (out_pcm ? stats_off : 0) + stats_bytes;
+    if (back_bytes && !hip_ok(ctx, hipMemcpyAsync(hout + back_off, dout + back_off, back_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H block")) break;
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
     if (out_pcm)
       for (uint32_t i = 0; i < num_streams; i++)
-        memcpy(out_pcm[i], (int16_t *)ctx->pcm_out.host + table[i].pcm_offset, (size_t)num_samples[i] * ch * sizeof(int16_t));
+        memcpy(out_pcm[i], reinterpret_cast<const int16_t *>(hout) + table[i].pcm_offset, (size_t)num_samples[i] * ch * sizeof(int16_t));
+    if (stats) memcpy(stats, hout + stats_off, stats_bytes);
     rc = AAD_APIRESULT_OK;
   } while (0);
   AADHip_ReconstructPlanDestroy(plan);

@@ -9,6 +9,7 @@
  * released in Destroy.  There is no CPU codec in this library: without a usable device those
  * three calls return AAD_APIRESULT_NG.
  */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -26,6 +27,60 @@ static int32_t default_device(void)
 {
   const char *e = getenv("AAD_HIP_DEVICE");
   return e != NULL ? (int32_t)atoi(e) : 0;
+}
+
+/*
+ * HIP contexts of the legacy handles.  The reference's callers create a handle per file
+ * (src/main.c:182-198: Create -> SetEncodeParameter -> EncodeWhole -> Destroy); a context per handle
+ * would pay a stream plus pinned and device staging allocations (milliseconds) for a kernel of tens
+ * of microseconds.  Destroy therefore parks the context in a small process-wide pool and the next
+ * handle's first encode / decode takes it from there, buffers and all.  A context is owned by one
+ * handle at a time, so distinct handles stay usable from distinct threads as in the reference.
+ * Parked contexts are left to process teardown (the HIP runtime may already be gone in an atexit).
+ */
+#define AAD_CONTEXT_POOL_SLOTS 8
+static pthread_mutex_t pool_lock = PTHREAD_MUTEX_INITIALIZER;
+static struct {
+  struct AADHipContext *context;
+  int32_t device;
+} pool[AAD_CONTEXT_POOL_SLOTS];
+
+static struct AADHipContext *acquire_context(void)
+{
+  const int32_t device = default_device();
+  struct AADHipContext *ctx = NULL;
+  int i;
+  pthread_mutex_lock(&pool_lock);
+  for (i = 0; i < AAD_CONTEXT_POOL_SLOTS && ctx == NULL; i++) {
+    if (pool[i].context != NULL && pool[i].device == device) {
+      ctx = pool[i].context;
+      pool[i].context = NULL;
+    }
+  }
+  pthread_mutex_unlock(&pool_lock);
+  if (ctx != NULL) {
+    AADHipInternal_ContextOptionsFromEnvironment(ctx); /* as a freshly created context would */
+    return ctx;
+  }
+  if (AADHip_ContextCreate(device, NULL, &ctx) != AAD_APIRESULT_OK) return NULL;
+  return ctx;
+}
+
+static void release_context(struct AADHipContext *ctx)
+{
+  int i;
+  if (ctx == NULL) return;
+  pthread_mutex_lock(&pool_lock);
+  for (i = 0; i < AAD_CONTEXT_POOL_SLOTS; i++) {
+    if (pool[i].context == NULL) {
+      pool[i].context = ctx;
+      pool[i].device = AADHipInternal_ContextDevice(ctx);
+      ctx = NULL;
+      break;
+    }
+  }
+  pthread_mutex_unlock(&pool_lock);
+  AADHip_ContextDestroy(ctx); /* pool full (NULL otherwise: a no-op) */
 }
 
 /* ============================================================================ encoder ==== */
@@ -88,7 +143,7 @@ struct AADEncoder *AADEncoder_Create(uint16_t max_block_size, void *work, int32_
 void AADEncoder_Destroy(struct AADEncoder *encoder)
 {
   if (encoder == NULL) return;
-  AADHip_ContextDestroy(encoder->context);
+  release_context(encoder->context);
   encoder->context = NULL;
   if (encoder->owns_work) free(encoder->work);
 }
@@ -112,11 +167,8 @@ AADApiResult AADEncoder_EncodeWhole(struct AADEncoder *encoder, const int32_t *c
                                     uint8_t *data, uint32_t data_size, uint32_t *output_size)
 {
   AADApiResult rc;
-  uint64_t need, produced = 0, capacity;
-  uint32_t ch, c, s;
-  int16_t *pcm;
-  const int16_t *pcm_list[1];
-  uint8_t *data_list[1];
+  uint64_t need, produced = 0;
+  uint32_t ch, c;
 
   if (encoder == NULL || input == NULL || data == NULL || output_size == NULL) return AAD_APIRESULT_INVALID_ARGUMENT;
   if (!encoder->set_parameter) return AAD_APIRESULT_PARAMETER_NOT_SET;
@@ -126,30 +178,13 @@ AADApiResult AADEncoder_EncodeWhole(struct AADEncoder *encoder, const int32_t *c
   need = AADFormat_EncodedSize(&encoder->header);
   if (data_size < need) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
 
-  if (encoder->context == NULL &&
-      AADHip_ContextCreate(default_device(), NULL, &encoder->context) != AAD_APIRESULT_OK)
-    return AAD_APIRESULT_NG;
+  if (encoder->context == NULL && (encoder->context = acquire_context()) == NULL) return AAD_APIRESULT_NG;
 
   ch = encoder->header.num_channels;
   for (c = 0; c < ch; c++)
     if (input[c] == NULL) return AAD_APIRESULT_INVALID_ARGUMENT;
-  pcm = (int16_t *)malloc(sizeof(int16_t) * (size_t)num_samples * ch);
-  if (pcm == NULL) return AAD_APIRESULT_NG;
-  /* planar int32 -> interleaved int16 (the device layout); samples must already be in int16
-   * range, which the reference only asserts (src/aad_encoder.c:612) - out-of-range input saturates */
-  for (c = 0; c < ch; c++) {
-    const int32_t *x = input[c];
-    for (s = 0; s < num_samples; s++) {
-      const int32_t v = x[s];
-      pcm[(size_t)s * ch + c] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
-    }
-  }
-  pcm_list[0] = pcm;
-  data_list[0] = data;
-  capacity = data_size;
-  rc = AADHip_EncodeBatch(encoder->context, &encoder->parameter, 1, pcm_list, &num_samples,
-                          data_list, &capacity, &produced, encoder->lane);
-  free(pcm);
+  rc = AADHipInternal_EncodePlanar32(encoder->context, &encoder->parameter, input, num_samples, data, data_size,
+                                     &produced, encoder->lane);
   if (rc != AAD_APIRESULT_OK) return rc;
   *output_size = (uint32_t)produced;
   return AAD_APIRESULT_OK;
@@ -188,7 +223,7 @@ struct AADDecoder *AADDecoder_Create(void *work, int32_t work_size)
 void AADDecoder_Destroy(struct AADDecoder *decoder)
 {
   if (decoder == NULL) return;
-  AADHip_ContextDestroy(decoder->context);
+  release_context(decoder->context);
   decoder->context = NULL;
   if (decoder->owns_work) free(decoder->work);
 }
@@ -218,12 +253,7 @@ static AADApiResult decode_into_planar(struct AADDecoder *decoder, int32_t has_f
                                        int32_t **buffer, uint32_t *got_frames)
 {
   const uint32_t ch = decoder->header.num_channels;
-  const uint8_t *data_list[1];
-  int16_t *pcm_list[1];
-  uint64_t size64 = data_size;
-  uint32_t decoded = 0, c, s;
-  AADApiResult rc;
-  int16_t *pcm;
+  uint32_t c;
 
   for (c = 0; c < ch; c++)
     if (buffer[c] == NULL) return AAD_APIRESULT_INVALID_ARGUMENT;
@@ -231,22 +261,9 @@ static AADApiResult decode_into_planar(struct AADDecoder *decoder, int32_t has_f
     *got_frames = 0;
     return AAD_APIRESULT_OK;
   }
-  if (decoder->context == NULL &&
-      AADHip_ContextCreate(default_device(), NULL, &decoder->context) != AAD_APIRESULT_OK)
-    return AAD_APIRESULT_NG;
-  pcm = (int16_t *)malloc(sizeof(int16_t) * (size_t)want_frames * ch);
-  if (pcm == NULL) return AAD_APIRESULT_NG;
-  data_list[0] = data;
-  pcm_list[0] = pcm;
-  rc = AADHipInternal_DecodeHost(decoder->context, &decoder->header, has_file_header, 1,
-                                 data_list, &size64, &want_frames, pcm_list, &decoded);
-  if (rc == AAD_APIRESULT_OK) {
-    for (c = 0; c < ch; c++)
-      for (s = 0; s < decoded; s++) buffer[c][s] = pcm[(size_t)s * ch + c];
-    *got_frames = decoded;
-  }
-  free(pcm);
-  return rc;
+  if (decoder->context == NULL && (decoder->context = acquire_context()) == NULL) return AAD_APIRESULT_NG;
+  return AADHipInternal_DecodePlanar32(decoder->context, &decoder->header, has_file_header, data, data_size,
+                                       want_frames, buffer, got_frames);
 }
 
 AADApiResult AADDecoder_DecodeBlock(struct AADDecoder *decoder, const uint8_t *data, uint32_t data_size,

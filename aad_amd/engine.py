@@ -8,8 +8,9 @@ import ctypes as C
 
 import numpy as np
 
-from .capi import (AADApiResult, AADHeaderInfo, ApiError, ERROR_STATS_DTYPE, LANE_STATE_DTYPE,
-                   RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL, STREAM_DESC_DTYPE, load_library, make_parameter)
+from .capi import (AADApiResult, AADHeaderInfo, ApiError, ERROR_STATS_DTYPE, LANE_MAPPINGS, LANE_STATE_DTYPE,
+                   OPTION_LANE_MAPPING, OPTION_TRIAL_LANES, RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL,
+                   STREAM_DESC_DTYPE, TRIAL_LANES, load_library, make_parameter)
 
 
 def _check(where, rc):
@@ -71,6 +72,16 @@ class Engine:
 
     def last_error(self):
         return (self.lib.AADHip_ContextLastError(self._ctx) or b"").decode()
+
+    def set_mapping(self, mapping="auto", trial_lanes=None):
+        """Force a lane mapping ("auto", "dense", "quad", "quad-fused") and, optionally, the trial
+        search's lane layout ("dual", "single") for every later run of this context
+        (AADHip_ContextSetOption; the environment is only read when the context is created)."""
+        _check("AADHip_ContextSetOption",
+               self.lib.AADHip_ContextSetOption(self._ctx, OPTION_LANE_MAPPING, LANE_MAPPINGS[mapping or "auto"]))
+        if trial_lanes is not None:
+            _check("AADHip_ContextSetOption",
+                   self.lib.AADHip_ContextSetOption(self._ctx, OPTION_TRIAL_LANES, TRIAL_LANES[trial_lanes]))
 
     def synchronize(self):
         _check("AADHip_ContextSynchronize", self.lib.AADHip_ContextSynchronize(self._ctx))

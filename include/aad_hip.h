@@ -68,6 +68,26 @@ AADApiResult AADHip_ContextSynchronize(struct AADHipContext *context);
 /* text of the last HIP failure seen by this context ("" if none); valid until the next call */
 const char *AADHip_ContextLastError(const struct AADHipContext *context);
 
+/* Launch options of a context.  Defaults: the environment variables AAD_HIP_MAPPING
+ * (auto | dense | quad | quad-fused) and AAD_HIP_TRIAL_LANES (dual | single), read ONCE when the
+ * context is created; the library never calls getenv afterwards.  An option holds for every later
+ * ...Run / ...Batch call of the context; set it from the thread that owns the context. */
+enum AADHipOption {
+  AAD_HIP_OPTION_LANE_MAPPING = 0, /* enum AADHipLaneMapping */
+  AAD_HIP_OPTION_TRIAL_LANES = 1   /* enum AADHipTrialLanes */
+};
+enum AADHipLaneMapping {
+  AAD_HIP_LANE_MAPPING_AUTO = 0,      /* by batch size (the default) */
+  AAD_HIP_LANE_MAPPING_DENSE = 1,     /* one lane per recurrence */
+  AAD_HIP_LANE_MAPPING_QUAD = 2,      /* four lanes per recurrence; decode: step-index scan on other waves */
+  AAD_HIP_LANE_MAPPING_QUAD_FUSED = 3 /* four lanes per recurrence; decode: one fused kernel */
+};
+enum AADHipTrialLanes {
+  AAD_HIP_TRIAL_LANES_DUAL = 0,  /* trial search on the quad mapping: the probe pass on lanes of its own */
+  AAD_HIP_TRIAL_LANES_SINGLE = 1 /* both strands on the same lanes */
+};
+AADApiResult AADHip_ContextSetOption(struct AADHipContext *context, int32_t option, int32_t value);
+
 /* bytes of the .aad image of a stream (header + full blocks + short tail); 0 on a bad parameter.
  * Same arithmetic as the write_offset AADEncoder_EncodeWhole ends with (src/aad_encoder.c:881-889). */
 uint64_t AADHip_CalculateEncodedSize(const struct AADEncodeParameter *parameter, uint32_t num_samples);

@@ -27,10 +27,7 @@ def engine():
 @pytest.mark.parametrize("seed", range(8))
 def test_random_parameter_sets(engine, mapping, seed):
     rng = np.random.default_rng(1000 + seed)
-    if mapping == "auto":
-        os.environ.pop("AAD_HIP_MAPPING", None)
-    else:
-        os.environ["AAD_HIP_MAPPING"] = mapping
+    engine.set_mapping(mapping)
     try:
         for _ in range(4):
             ch = int(rng.choice([1, 2, 2, 2, 3, 5, 8]))
@@ -59,4 +56,4 @@ def test_random_parameter_sets(engine, mapping, seed):
             for i, (got, w) in enumerate(zip(decoded, want)):
                 assert np.array_equal(got, ob.decode(w)[0]), (seed, mapping, ch, bits, ms, trials, mbs, lengths[i])
     finally:
-        os.environ.pop("AAD_HIP_MAPPING", None)
+        engine.set_mapping("auto")

@@ -31,13 +31,16 @@ def engine():
 
 
 @pytest.fixture(params=["dense", "quad", "quad-fused"])
-def mapping(request):
+def mapping(request, engine):
     """The lane mappings of the kernels (one lane per recurrence / four lanes per recurrence; for the
-    quad decoder both the two-kernel form and the single fused kernel):
-    the host picks by batch size, AAD_HIP_MAPPING forces one (read at every launch)."""
+    quad decoder both the two-kernel form and the single fused kernel): the host picks by batch
+    size, a context option forces one (AADHip_ContextSetOption).  The environment variable is the
+    option's default for contexts created from here on - the legacy API's handles."""
+    engine.set_mapping(request.param)
     os.environ["AAD_HIP_MAPPING"] = request.param
     yield request.param
     os.environ.pop("AAD_HIP_MAPPING", None)
+    engine.set_mapping("auto")
 
 
 @pytest.fixture(scope="module")
@@ -79,8 +82,7 @@ def test_trial_search_lane_layouts(engine, lanes):
     """The trial search on the quad mapping with its probe strand on lanes of its own ("dual", the
     host's choice for streams of three blocks and more) and on the chain's lanes ("single"): every
     golden case with trials, single- and many-block streams alike, under both."""
-    os.environ["AAD_HIP_MAPPING"] = "quad"
-    os.environ["AAD_HIP_TRIAL_LANES"] = lanes
+    engine.set_mapping("quad", lanes)
     try:
         groups = {}
         for c in MANIFEST["cases"]:
@@ -93,8 +95,7 @@ def test_trial_search_lane_layouts(engine, lanes):
             for c, img in zip(cases, images):
                 assert sha256(img) == c["aad_sha256"], (lanes, c["name"])
     finally:
-        os.environ.pop("AAD_HIP_MAPPING", None)
-        os.environ.pop("AAD_HIP_TRIAL_LANES", None)
+        engine.set_mapping("auto", "dual")
 
 
 @pytest.mark.parametrize("corpus", MANIFEST["corpora"], ids=lambda c: c["name"])
@@ -265,13 +266,13 @@ def test_config5_full_size_10000_files(engine):
     d_pcm = torch.from_numpy(pcm).cuda()
     results = {}
     for mode in ("dense", "quad"):
-        os.environ["AAD_HIP_MAPPING"] = mode
+        engine.set_mapping(mode)
         try:
             d_img, size = engine.encode_uniform(d_pcm, param)
             d_dec, hd = engine.decode_uniform(d_img, size)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("AAD_HIP_MAPPING", None)
+            engine.set_mapping("auto")
         results[mode] = (_hash_rows(d_img.cpu().numpy()), _hash_rows(d_dec.cpu().numpy()))
         assert size == 31 + 10 * 1024
     assert results["dense"] == results["quad"]
@@ -378,12 +379,12 @@ def test_extreme_block_sizes(engine, mapping):
 
 @pytest.mark.parametrize("streams,bits,ch", [(3000, 4, 2), (7000, 4, 1), (9000, 3, 2), (12000, 2, 2)])
 def test_decode_mapping_ranges_auto(engine, streams, bits, ch):
-    """The host's own choice of decode mapping across its thresholds (no AAD_HIP_MAPPING): split
+    """The host's own choice of decode mapping across its thresholds (mapping option "auto"): split
     decoder with the residuals in a device scratch buffer (more than one workgroup per CU),
     fused quad kernel, dense kernel - one-block streams, sampled against the oracle, and the whole
     batch through the round trip decode(encode(x)) == oracle decode."""
     import torch
-    os.environ.pop("AAD_HIP_MAPPING", None)
+    engine.set_mapping("auto")
     spb = {4: 1984, 3: 2632, 2: 3960}[bits] // ch
     base = synth_pcm(500, spb, ch, seed=2024 + streams)
     pcm = np.concatenate([base] * (-(-streams // 500)))[:streams]

@@ -16,7 +16,7 @@ param = make_parameter(2, 4, 1024, 48000, False, 0)
 base = torch.from_numpy(synth_pcm(1000, 992, 2, seed=1234)).cuda()
 for streams in (500, 1000, 2000, 3000, 4000, 6000, 8000, 12000, 16000):
     pcm = base.repeat((-(-streams // 1000), 1, 1))[:streams].contiguous()
-    os.environ.pop("AAD_HIP_MAPPING", None)
+    engine.set_mapping("auto")
     plan = engine.uniform_encode_plan(param, streams, 992)
     img = torch.zeros((streams, plan.stride), dtype=torch.uint8, device="cuda")
     plan.run(pcm, img)
@@ -24,7 +24,7 @@ for streams in (500, 1000, 2000, 3000, 4000, 6000, 8000, 12000, 16000):
     hd = parse_header(bytes(img[0, :31].cpu().numpy()))
     row = dict(streams=streams, recurrences=2 * streams)
     for mapping in ("quad", "quad-fused", "dense"):
-        os.environ["AAD_HIP_MAPPING"] = mapping
+        engine.set_mapping(mapping)
         dplan = engine.uniform_decode_plan(hd, streams, plan.stride, plan.image_size)
         out = torch.zeros_like(pcm)
         for _ in range(3):
