@@ -3,11 +3,20 @@
 Streams are independent, so the codec itself needs no collective: every rank encodes (or
 decodes) its own shard with its own engine.  RCCL (torch.distributed backend "nccl" on ROCm)
 is used only around the data path, and only when a single rank owns the files:
-  * the job table (file lengths + parameters) is broadcast from the root,
+  * the job table (file lengths) is broadcast from the root,
   * the encoded images are gathered to the root, which writes them out in job order.
 Image sizes follow from the lengths (AADHip_CalculateEncodedSize), so every rank can compute all
-offsets without an exchange.  With gloo the same code runs on CPU tensors (used by the tests,
-with a test double in place of the engine - the product has no CPU codec).
+offsets without an exchange.
+
+Two shard encoders:
+  encode_sharded_device  the product path: the shard's PCM is resident in HBM, the engine's plan
+                         writes the images STRAIGHT INTO the rank's gather row (a device tensor),
+                         dist.gather moves rows device-to-device (xGMI under RCCL) and the root
+                         makes ONE device-to-host copy of what it received;
+  encode_sharded         host-memory shards through a caller-supplied encode_fn
+                         (Engine.encode_host bound to a parameter in production; the CPU tests
+                         pass an oracle-based double - the product has no CPU codec).
+With the gloo backend the same code runs on CPU tensors (rows are moved to the host first).
 """
 import numpy as np
 
@@ -26,26 +35,116 @@ def partition_lpt(costs, world):
     return [sorted(b) for b in bins]
 
 
-class BatchCodec:
-    """encode_fn(list of int16 [samples, channels] arrays) -> list of bytes, for one parameter set.
-    In production encode_fn is Engine.encode_host bound to an AADEncodeParameter."""
+def _round_up(v, a):
+    return (v + a - 1) // a * a
 
-    def __init__(self, encode_fn, rank=0, world=1, dist=None, device="cpu"):
-        self.encode_fn, self.rank, self.world, self.dist, self.device = encode_fn, rank, world, dist, device
+
+class BatchCodec:
+    def __init__(self, encode_fn=None, rank=0, world=1, dist=None, device="cpu", engine=None):
+        """encode_fn(list of int16 [samples, channels] arrays) -> list of bytes (host shards);
+        engine: an aad_amd.Engine (device shards).  device: where collective tensors live -
+        "cuda:N" with the nccl backend, "cpu" with gloo."""
+        self.encode_fn, self.rank, self.world, self.dist, self.device, self.engine = encode_fn, rank, world, dist, device, engine
+
+    # ---- collectives ----------------------------------------------------------------------
+    def _collective_device(self):
+        return self.device if self.dist is not None and self.dist.get_backend() == "nccl" else "cpu"
 
     def broadcast_table(self, lengths, root=0):
         """lengths: samples per file on the root (ignored elsewhere) -> int64 array on every rank"""
         import torch
         if self.world == 1:
             return np.asarray(lengths, dtype=np.int64)
-        n = torch.tensor([len(lengths) if self.rank == root else 0], dtype=torch.int64, device=self.device)
+        dev = self._collective_device()
+        n = torch.tensor([len(lengths) if self.rank == root else 0], dtype=torch.int64, device=dev)
         self.dist.broadcast(n, src=root)
-        t = torch.zeros(int(n.item()), dtype=torch.int64, device=self.device)
+        t = torch.zeros(int(n.item()), dtype=torch.int64, device=dev)
         if self.rank == root:
             t.copy_(torch.as_tensor(np.asarray(lengths, dtype=np.int64)))
         self.dist.broadcast(t, src=root)
         return t.cpu().numpy()
 
+    def _gather_rows(self, send, root):
+        """send: uint8 tensor, the same length on every rank -> list of uint8 numpy rows on the root
+        (None elsewhere).  The rows travel as they are (device tensors under nccl)."""
+        import torch
+        dev = self._collective_device()
+        if str(send.device) != str(torch.device(dev)):
+            send = send.to(dev)
+        recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == root else None
+        self.dist.gather(send, recv, dst=root)
+        if self.rank != root:
+            return None
+        return torch.stack(recv).cpu().numpy()  # one device-to-host copy of everything received
+
+    @staticmethod
+    def _row_layout(shards, sizes):
+        """16-byte aligned offsets of every image inside its rank's row, and the common row length"""
+        offsets, row = {}, 1
+        for s in shards:
+            pos = 0
+            for i in s:
+                offsets[i] = pos
+                pos += _round_up(sizes[i], 16)
+            row = max(row, pos)
+        return offsets, row
+
+    def _unpack(self, rows, shards, sizes, offsets):
+        out = [None] * len(sizes)
+        for r, s in enumerate(shards):
+            for i in s:
+                out[i] = bytes(rows[r][offsets[i]:offsets[i] + sizes[i]])
+        return out
+
+    # ---- device-resident shards (the product path) -----------------------------------------------
+    def encode_sharded_device(self, param, lengths, shard_pcm, root=0, return_rows=False):
+        """Encode all files of the table.  shard_pcm(indices) returns this rank's PCM in HBM: an
+        int16 cuda tensor [len(indices), samples, channels] (equal lengths) or a list of
+        [samples_i, channels] tensors.  Returns the images in job order on the root (or, with
+        return_rows, the raw gathered rows plus the layout - no per-file Python work), None elsewhere."""
+        import torch
+        from .capi import STREAM_DESC_DTYPE
+        eng = self.engine
+        lengths = np.asarray(lengths, dtype=np.int64)
+        shards = partition_lpt(lengths, self.world)
+        sizes = [eng.encoded_size(param, int(n)) for n in lengths]
+        offsets, row = self._row_layout(shards, sizes)
+        mine = shards[self.rank]
+        send = torch.zeros(row, dtype=torch.uint8, device="cuda:%d" % eng.device)
+        if mine:
+            pcm = shard_pcm(mine)
+            ch = param.num_channels
+            d = np.zeros(len(mine), dtype=STREAM_DESC_DTYPE)
+            if isinstance(pcm, (list, tuple)):
+                starts = np.cumsum([0] + [_round_up(int(p.shape[0]) * ch, 8) for p in pcm])
+                flat = torch.zeros(int(starts[-1]), dtype=torch.int16, device=send.device)
+                for k, p in enumerate(pcm):
+                    flat[int(starts[k]):int(starts[k]) + p.numel()] = p.reshape(-1)
+                d["pcm_offset"] = starts[:-1]
+            else:
+                assert pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.shape[0] == len(mine)
+                flat = pcm
+                d["pcm_offset"] = np.arange(len(mine), dtype=np.uint64) * np.uint64(pcm.shape[1] * ch)
+            d["data_offset"] = [offsets[i] for i in mine]
+            d["data_size"] = [_round_up(sizes[i], 16) for i in mine]
+            d["num_samples"] = [int(lengths[i]) for i in mine]
+            plan = eng.encode_plan(param, d)
+            try:
+                plan.run(flat, send, None)
+                torch.cuda.current_stream().synchronize()
+            finally:
+                plan.close()
+        if self.world == 1:
+            rows = send.cpu().numpy()[None, :]
+        else:
+            rows = self._gather_rows(send, root)
+            if self.rank != root:
+                return None
+        if return_rows:
+            return rows, shards, sizes, offsets
+        return self._unpack(rows, shards, sizes, offsets)
+
+    # ---- host-memory shards -------------------------------------------------------------------
     def encode_sharded(self, lengths, load_pcm, image_size, root=0):
         """Encode all files of the table.  load_pcm(i) returns file i's PCM on the rank that owns
         it; image_size(n) is the encoded size for n samples.  Returns the list of images in job
@@ -60,23 +159,11 @@ class BatchCodec:
             assert len(img) == sizes[i], "image size differs from the format arithmetic"
         if self.world == 1:
             return images
-        # one padded byte row per rank; sizes are static so no size exchange is needed
-        shard_bytes = [sum(sizes[i] for i in s) for s in shards]
-        row = max(shard_bytes + [1])
-        send = torch.zeros(row, dtype=torch.uint8, device=self.device)
-        if images:
-            blob = np.frombuffer(b"".join(images), dtype=np.uint8)
-            send[: len(blob)] = torch.as_tensor(blob.copy()).to(self.device)
-        recv = [torch.zeros(row, dtype=torch.uint8, device=self.device) for _ in range(self.world)] \
-            if self.rank == root else None
-        self.dist.gather(send, recv, dst=root)
+        offsets, row = self._row_layout(shards, sizes)  # sizes are static: no size exchange
+        send = np.zeros(row, dtype=np.uint8)
+        for i, img in zip(mine, images):
+            send[offsets[i]:offsets[i] + sizes[i]] = np.frombuffer(img, dtype=np.uint8)
+        rows = self._gather_rows(torch.from_numpy(send), root)
         if self.rank != root:
             return None
-        out = [None] * len(lengths)
-        for r, s in enumerate(shards):
-            buf = recv[r].cpu().numpy()
-            pos = 0
-            for i in s:
-                out[i] = bytes(buf[pos:pos + sizes[i]])
-                pos += sizes[i]
-        return out
+        return self._unpack(rows, shards, sizes, offsets)

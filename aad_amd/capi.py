@@ -78,7 +78,8 @@ HIP_SYMBOLS = [
     "AADHip_ReconstructPlanCreate", "AADHip_ReconstructPlanDestroy", "AADHip_ReconstructPlanRun",
     "AADHip_ReconstructBatch",
 ]
-WAV_SYMBOLS = ["AADWav_ParseHeader", "AADWav_WriteHeader"]
+WAV_SYMBOLS = ["AADWav_ParseHeader", "AADWav_WriteHeader", "AADWav_ConvertToPcm16"]
+SYNTH_SYMBOLS = ["AADSynth_Generate"]
 
 
 class AADWavInfo(C.Structure):  # include/aad_wav.h
@@ -165,6 +166,8 @@ def _declare_hip(lib):
     lib.AADWav_ParseHeader.restype = C.c_int
     lib.AADWav_WriteHeader.argtypes = [vp, C.c_uint32, C.c_uint16, C.c_uint32, C.c_uint32]
     lib.AADWav_WriteHeader.restype = C.c_int
+    lib.AADWav_ConvertToPcm16.argtypes = [vp, C.c_uint16, C.c_uint64, vp]
+    lib.AADWav_ConvertToPcm16.restype = C.c_int
 
 
 def load_library(path=None, hip=True):

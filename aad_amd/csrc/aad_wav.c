@@ -62,3 +62,24 @@ AADApiResult AADWav_WriteHeader(uint8_t *d, uint32_t data_size, uint16_t num_cha
   put32(d + 40, bytes);
   return AAD_APIRESULT_OK;
 }
+
+AADApiResult AADWav_ConvertToPcm16(const uint8_t *p, uint16_t bits, uint64_t count, int16_t *pcm)
+{
+  uint64_t i;
+  if (p == NULL || pcm == NULL) return AAD_APIRESULT_INVALID_ARGUMENT;
+  switch (bits) {
+    case 8:
+      for (i = 0; i < count; i++) pcm[i] = (int16_t)(((int32_t)p[i] - 128) * 256);
+      return AAD_APIRESULT_OK;
+    case 16:
+    case 24:
+    case 32: {
+      const uint32_t step = bits / 8u;
+      p += step - 2; /* the two most significant bytes of every little-endian sample */
+      for (i = 0; i < count; i++, p += step) pcm[i] = (int16_t)le16(p);
+      return AAD_APIRESULT_OK;
+    }
+    default:
+      return AAD_APIRESULT_INVALID_FORMAT;
+  }
+}

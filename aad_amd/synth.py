@@ -30,10 +30,41 @@ def _tri(phase):
     return 2 * v - 32767
 
 
-def synth_pcm(num_streams, num_samples, channels, seed=1234, rate=48000, kind="music", first_stream=0):
+_KINDS = {"music": 0, "noise": 1, "nyquist": 2}  # enum AADSynthKind (include/aad_synth.h)
+_native = None
+
+
+def _native_generator():
+    """AADSynth_Generate from libaad_hip.so (aad_amd/csrc/aad_synth.c, the same arithmetic in C) or
+    False when the library has not been built."""
+    global _native
+    if _native is None:
+        try:
+            import ctypes as C
+            from .capi import LIBRARY_PATH
+            fn = C.CDLL(LIBRARY_PATH).AADSynth_Generate
+            fn.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int32, C.c_uint64]
+            fn.restype = C.c_int32
+            _native = fn
+        except (OSError, AttributeError):
+            _native = False
+    return _native
+
+
+def synth_pcm(num_streams, num_samples, channels, seed=1234, rate=48000, kind="music", first_stream=0,
+              native=True):
     """kind: "music" (two partials + noise, |x| <~ 0.63 FS), "noise" (full-scale white
     noise) or "nyquist" (full-scale square at fs/2) - the two stress shapes of
-    reference test/test_aad_encode_decode.c:447-451, 467-470."""
+    reference test/test_aad_encode_decode.c:447-451, 467-470.  native=False forces the numpy
+    form below (the specification); by default the C form of the same arithmetic is used."""
+    if kind not in _KINDS:
+        raise ValueError(kind)
+    fn = _native_generator() if native else False
+    if fn:
+        out = np.empty((num_streams, num_samples, channels), dtype=np.int16)
+        if out.size and fn(out.ctypes.data, num_streams, num_samples, channels, seed, rate, _KINDS[kind], first_stream) != 0:
+            raise ValueError("AADSynth_Generate refused its arguments")
+        return out
     s = np.arange(first_stream, first_stream + num_streams, dtype=np.uint64)[:, None]
     c = np.arange(channels, dtype=np.uint64)[None, :]
     with np.errstate(over="ignore"):

@@ -39,6 +39,12 @@ AADApiResult AADWav_ParseHeader(const uint8_t *data, uint64_t data_size, struct 
 AADApiResult AADWav_WriteHeader(uint8_t *data, uint32_t data_size, uint16_t num_channels,
                                 uint32_t sampling_rate, uint32_t num_samples);
 
+/* 8 / 16 / 24 / 32-bit little-endian PCM -> the int16 the codec sees.  The reference reader widens
+ * every sample to 32 bits (src/wav.c:392-417: 8-bit (v - 128) << 24, 16-bit << 16, 24-bit << 8) and
+ * the CLI keeps the top 16 of those (src/main.c:175-179), i.e. 8-bit: (v - 128) << 8; 24- and 32-bit:
+ * the two most significant bytes.  `count` = frames * channels.  INVALID_FORMAT for other widths. */
+AADApiResult AADWav_ConvertToPcm16(const uint8_t *payload, uint16_t bits_per_sample, uint64_t count, int16_t *pcm);
+
 #ifdef __cplusplus
 }
 #endif

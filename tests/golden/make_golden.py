@@ -83,7 +83,16 @@ def main():
                                                 ("cfg2_stereo4_1000x1blk_t2", 1000, 992, 2, 4, 2),
                                                 ("cfg4ref_stereo3_2000x1blk_t0", 2000, 1316, 2, 3, 0),
                                                 ("cfg4ref_stereo2_2000x1blk_t0", 2000, 1980, 2, 2, 0),
-                                                ("cfg5_stereo4_100x10blk_t0", 100, 9920, 2, 4, 0)):
+                                                ("cfg5_stereo4_100x10blk_t0", 100, 9920, 2, 4, 0),
+                                                # long in-lane block chains (src/aad_encoder.c:853-886, header carry :645-653)
+                                                ("cfg2iii_stereo4_1x1000blk_t0", 1, 992000, 2, 4, 0),
+                                                ("cfg2iii_stereo4_1x1000blk_t2", 1, 992000, 2, 4, 2),
+                                                ("cfg2ii_stereo4_1000x16blk_t0", 1000, 15872, 2, 4, 0),
+                                                ("cfg5_stereo4_1250x10blk_t0", 1250, 9920, 2, 4, 0),
+                                                ("chain_stereo4_40x25blk_t2", 40, 24800 - 77, 2, 4, 2),
+                                                ("chain_mono2_200x5blk_t0", 200, 20140, 1, 2, 0),
+                                                ("chain_mono2_60x5blk_t2", 60, 20140 - 1001, 1, 2, 2),
+                                                ("chain_mono3_100x4blk_t1", 100, 4 * 2684 - 100, 1, 3, 1)):
         pcm = synth_pcm(streams, n, ch, seed=1234)
         h_aad, h_dec = hashlib.sha256(), hashlib.sha256()
         size = 0
@@ -98,6 +107,20 @@ def main():
                             aad_concat_sha256=h_aad.hexdigest(), decoded_concat_sha256=h_dec.hexdigest()))
     manifest["corpora"] = corpora
 
+    # BASELINE config 5 at full size (10 000 stereo 4-bit files x 10 blocks), for bench.py's batched-file
+    # leg at 1 / 2 / 4 / 8 ranks x 1250 files: SHA-256 of the images of the first N files, in job order
+    pcm_hash, h = hashlib.sha256(), hashlib.sha256()
+    prefix = {}
+    for s in range(10000):
+        pcm = synth_pcm(1, 9920, 2, seed=1234, first_stream=s)[0]
+        pcm_hash.update(pcm.tobytes())
+        h.update(ref.encode(pcm, 4, 1024, 48000, False, 0))
+        if s + 1 in (1250, 2500, 5000, 10000):
+            prefix[str(s + 1)] = h.copy().hexdigest()
+    manifest["file_corpora"] = [dict(name="cfg5_stereo4_10000x10blk_t0", streams=10000, samples=9920, channels=2, bits=4,
+                                     trials=0, max_block_size=1024, seed=1234, image_bytes=10271,
+                                     pcm_sha256=pcm_hash.hexdigest(), aad_prefix_sha256=prefix)]
+
     # 8-channel container extension: the reference cannot produce it, so each
     # channel is pinned as a mono stream whose block geometry equals the 8-channel one.
     eight = []
@@ -110,9 +133,29 @@ def main():
                                   seed=77, aad_sha256=sha(aad)))
     manifest["eight_channel_as_mono"] = eight
 
+    # BASELINE config 4 at full size: 10 000 eight-channel one-block segments, 3- and 2-bit, pinned
+    # the same way - every (segment, channel) as the reference's mono image, hashed in that order
+    eight_corpora = []
+    for bits, spb, block_size, mono_bs in ((3, 292, 1008, 126), (2, 444, 1024, 128), (4, 224, 1024, 128)):
+        streams = 10000 if bits != 4 else 1000
+        pcm = synth_pcm(streams, spb, 8, seed=1234)
+        h = hashlib.sha256()
+        size = 0
+        for s in range(streams):
+            for c in range(8):
+                aad = ref.encode(pcm[s][:, c:c + 1], bits, 128, 48000, False, 0)
+                h.update(aad)
+                size = len(aad)
+        eight_corpora.append(dict(name="cfg4_8ch_b%d_%dx1blk_t0" % (bits, streams), streams=streams, samples=spb,
+                                  channels=8, bits=bits, trials=0, max_block_size=1024, block_size=block_size,
+                                  mono_max_block_size=128, mono_block_size=mono_bs, mono_image_bytes=size, seed=1234,
+                                  pcm_sha256=sha(pcm.tobytes()), mono_images_concat_sha256=h.hexdigest()))
+    manifest["eight_channel_corpora"] = eight_corpora
+
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
-    print("cases:", len(manifest["cases"]), "corpora:", len(corpora), "8ch lanes:", len(eight))
+    print("cases:", len(manifest["cases"]), "corpora:", len(corpora), "8ch lanes:", len(eight),
+          "8ch corpora:", len(eight_corpora))
 
 
 if __name__ == "__main__":

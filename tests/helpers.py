@@ -59,3 +59,32 @@ def cli_mode_input(case):
         data = wav16_bytes(pcm, rate)
     assert sha256(data) == case["input_sha256"]
     return pcm, rate, data
+
+
+def wav_bytes_depth(pcm, rate, depth, salt=0):
+    """A PCM WAV image of `depth` bits per sample (8 / 16 / 24 / 32) whose top 16 bits per sample are
+    `pcm` (int16 [samples, channels]) - 8-bit keeps only the top byte - and whose lower bits are
+    deterministic filler (an LCG seeded by `salt`), so that a reader which does not discard them by
+    the reference's rule (src/main.c:175-179, src/wav.c:392-417) gives different codes."""
+    pcm = np.ascontiguousarray(pcm, dtype="<i2")
+    n, ch = pcm.shape
+    flat = pcm.reshape(-1).astype(np.int64)
+    x = (np.arange(flat.size, dtype=np.uint64) * np.uint64(6364136223846793005) + np.uint64(1442695040888963407 + salt))
+    low = ((x >> np.uint64(40)) & np.uint64(0xFFFF)).astype(np.int64)
+    if depth == 8:
+        payload = (((flat >> 8) + 128) & 0xFF).astype(np.uint8).tobytes()
+    elif depth == 16:
+        payload = pcm.tobytes()
+    elif depth == 24:
+        v = ((flat << 8) | (low & 0xFF)) & 0xFFFFFF
+        b = np.empty((flat.size, 3), dtype=np.uint8)
+        b[:, 0], b[:, 1], b[:, 2] = v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF
+        payload = b.tobytes()
+    elif depth == 32:
+        payload = (((flat << 16) | low) & 0xFFFFFFFF).astype("<u4").tobytes()
+    else:
+        raise ValueError(depth)
+    bps = depth // 8
+    head = b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 1, ch, rate, rate * bps * ch, bps * ch, depth) + b"data" + struct.pack("<I", len(payload))
+    return head + payload

@@ -1,0 +1,116 @@
+"""Batched-file mode (BASELINE config 5) with the REAL engine under a 2-rank
+process group on the one-GPU box: both ranks drive cuda:0 (as bench.py does with
+LOCAL_RANK % device_count).  gloo must pass; nccl (= RCCL) is tried as well and reported as skipped
+when RCCL refuses two ranks on one device.  What is under test: aad_amd/batch.py's device path -
+table broadcast, LPT sharding, the engine's plan writing straight into the gather row, the gather,
+the root's re-assembly in job order - against the compiled reference's hashes.
+The 1 -> N scaling curve itself is NOT measured here (no multi-GPU node in this pool)."""
+import hashlib
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MANIFEST = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, backend, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from aad_amd.batch import BatchCodec
+    from aad_amd.capi import make_parameter
+    from aad_amd.engine import Engine
+    from aad_amd.synth import synth_pcm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    try:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    except Exception as e:  # RCCL may refuse a duplicate device
+        q.put(("unsupported", repr(e)))
+        return
+    try:
+        eng = Engine(0)
+        codec = BatchCodec(rank=rank, world=world, dist=dist, device="cuda:0", engine=eng)
+        param = make_parameter(2, 4, 1024, 48000, False, 0)
+        try:
+            # (a) BASELINE config 5's shape: 100 equal files x 10 blocks (uniform device tensor per shard)
+            lengths = [9920] * 100
+            table = codec.broadcast_table(lengths if rank == 0 else [], root=0)
+            assert list(table) == lengths
+            out = codec.encode_sharded_device(
+                param, table, lambda idx: torch.from_numpy(np.stack([synth_pcm(1, 9920, 2, seed=1234, first_stream=i)[0] for i in idx])).cuda())
+            digest_a = hashlib.sha256(b"".join(out)).hexdigest() if rank == 0 else None
+            # (b) ragged lengths (list of device tensors per shard), LPT-dealt
+            ragged = [992, 5000, 3, 9920, 1500, 992, 20000, 4, 77]
+            table = codec.broadcast_table(ragged if rank == 0 else [], root=0)
+            out = codec.encode_sharded_device(
+                param, table, lambda idx: [torch.from_numpy(synth_pcm(1, int(table[i]), 2, seed=1234, first_stream=i)[0]).cuda() for i in idx])
+            digests_b = [hashlib.sha256(b).hexdigest() for b in out] if rank == 0 else None
+            # (c) host-memory shards through Engine.encode_host
+            codec.encode_fn = lambda pcms: eng.encode_host(pcms, param)
+            out = codec.encode_sharded(table, lambda i: synth_pcm(1, int(table[i]), 2, seed=1234, first_stream=i)[0],
+                                       lambda n: eng.encoded_size(param, n))
+            digests_c = [hashlib.sha256(b).hexdigest() for b in out] if rank == 0 else None
+        except Exception as e:
+            if backend == "nccl" and rank == 0:
+                q.put(("unsupported", repr(e)))
+                return
+            raise
+        if rank == 0:
+            q.put(("ok", digest_a, digests_b, digests_c))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_one_gpu_real_engine(backend):
+    import torch.multiprocessing as mp
+    import oracle_binding as ob
+    from aad_amd.synth import synth_pcm
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        got = q.get(timeout=240)
+    except Exception:
+        got = ("timeout",)
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.terminate()  # exactly the processes started above
+            p.join(10)
+    if got[0] != "ok":
+        if backend == "nccl":
+            pytest.skip("RCCL with two ranks on one device: %s" % (got[1] if len(got) > 1 else got[0]))
+        pytest.fail(str(got))
+    for p in procs:
+        assert p.exitcode == 0
+    _, digest_a, digests_b, digests_c = got
+    corpus = [c for c in MANIFEST["corpora"] if c["name"] == "cfg5_stereo4_100x10blk_t0"][0]
+    assert digest_a == corpus["aad_concat_sha256"]  # the compiled reference's images, in job order
+    ragged = [992, 5000, 3, 9920, 1500, 992, 20000, 4, 77]
+    want = [hashlib.sha256(ob.encode(synth_pcm(1, n, 2, seed=1234, first_stream=i)[0], 4, 1024)).hexdigest()
+            for i, n in enumerate(ragged)]
+    assert digests_b == want and digests_c == want

@@ -117,6 +117,48 @@ def test_baseline_corpora_device_resident(engine, corpus, mapping):
     assert sha256(d_dec.cpu().numpy().tobytes()) == corpus["decoded_concat_sha256"]
 
 
+@pytest.mark.parametrize("lanes", ["dual", "single"])
+def test_long_chains_with_trial_search_both_lane_layouts(engine, lanes):
+    """Long in-lane block chains WITH the trial search (1 stream x 1000 blocks, 40 x 25, mono 2-/3-bit
+    multi-block) on the quad mapping under both trial-lane layouts, against the reference's hashes
+    (src/aad_encoder.c:853-886 block chain, :470-562 search, :645-653 header carry)."""
+    import torch
+    engine.set_mapping("quad", lanes)
+    try:
+        corpora = [c for c in MANIFEST["corpora"] if c["trials"]]
+        assert len(corpora) >= 4
+        for corpus in corpora:
+            pcm = synth_pcm(corpus["streams"], corpus["samples"], corpus["channels"], seed=corpus["seed"])
+            param = make_parameter(corpus["channels"], corpus["bits"], 1024, 48000, False, corpus["trials"])
+            d_img, size = engine.encode_uniform(torch.from_numpy(pcm).cuda(), param)
+            torch.cuda.synchronize()
+            img = d_img.cpu().numpy()
+            assert sha256(np.ascontiguousarray(img[:, :size]).tobytes()) == corpus["aad_concat_sha256"], (lanes, corpus["name"])
+    finally:
+        engine.set_mapping("auto", "dual")
+
+
+@pytest.mark.parametrize("corpus", MANIFEST["eight_channel_corpora"], ids=lambda c: c["name"])
+def test_config4_eight_channel_corpora(engine, corpus):
+    """BASELINE config 4 at full size: 10 000 eight-channel one-block segments (3- and 2-bit; 4-bit
+    at 1000), every (segment, channel) hashed as the mono image the compiled reference produced
+    for that channel (tests/golden/make_golden.py), and the decode checked against the oracle."""
+    import hashlib
+    import torch
+    from aad_amd.reframe import channels_as_mono_images
+    pcm = synth_pcm(corpus["streams"], corpus["samples"], 8, seed=corpus["seed"])
+    assert sha256(pcm.tobytes()) == corpus["pcm_sha256"]
+    d_img, size = engine.encode_uniform(torch.from_numpy(pcm).cuda(), make_parameter(8, corpus["bits"], 1024))
+    d_dec, _ = engine.decode_uniform(d_img, size)
+    torch.cuda.synchronize()
+    img = np.ascontiguousarray(d_img.cpu().numpy()[:, :size])
+    mono = channels_as_mono_images(img, 8, corpus["bits"], corpus["block_size"], corpus["mono_block_size"])
+    assert hashlib.sha256(np.ascontiguousarray(mono).tobytes()).hexdigest() == corpus["mono_images_concat_sha256"]
+    dec = d_dec.cpu().numpy()
+    for s in range(0, corpus["streams"], 501):
+        assert np.array_equal(dec[s], ob.decode(bytes(img[s]))[0]), s
+
+
 def test_eight_channel_lanes_equal_reference_mono(engine):
     from test_oracle_golden import extract_channel_as_mono
     for bits in (4, 3, 2):

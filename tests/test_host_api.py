@@ -10,7 +10,7 @@ import pytest
 
 import aad_amd
 from aad_amd import AADApiResult as R
-from aad_amd.capi import (HIP_SYMBOLS, LEGACY_SYMBOLS, WAV_SYMBOLS, AADEncodeParameter, AADHeaderInfo, AADWavInfo,
+from aad_amd.capi import (HIP_SYMBOLS, LEGACY_SYMBOLS, SYNTH_SYMBOLS, WAV_SYMBOLS, AADEncodeParameter, AADHeaderInfo, AADWavInfo,
                           make_parameter)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,10 +23,10 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     declared = set()
-    for h in ("aad_api.h", "aad_hip.h", "aad_wav.h"):
+    for h in ("aad_api.h", "aad_hip.h", "aad_wav.h", "aad_synth.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
-        declared |= set(re.findall(r"\b(AAD(?:Encoder|Decoder|Hip|Wav)_[A-Za-z]+)\s*\(", text))
-    assert declared == set(LEGACY_SYMBOLS) | set(HIP_SYMBOLS) | set(WAV_SYMBOLS)
+        declared |= set(re.findall(r"\b(AAD(?:Encoder|Decoder|Hip|Wav|Synth)_[A-Za-z0-9]+)\s*\(", text))
+    assert declared == set(LEGACY_SYMBOLS) | set(HIP_SYMBOLS) | set(WAV_SYMBOLS) | set(SYNTH_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
 
@@ -249,6 +249,40 @@ def test_hip_api_without_device_fails_loudly(lib):
     with pytest.raises(RuntimeError):
         from aad_amd.engine import Engine
         Engine()
+
+
+def test_decode_plan_refuses_unbounded_blocks(lib):
+    """The decoder's header checks (reference src/aad_decoder.c:173-225) accept any samples-per-block;
+    the device's per-block loop counters are 32-bit and step by up to a pack unit (8 for 3-bit), so
+    plan creation refuses a stream whose single block would hold 2^31 samples or more
+    (AADFormat_DecodeWorkBounded, the host rule behind AADHip_DecodePlanCreate / DecodeBatch)."""
+    lib.AADFormat_DecodeWorkBounded.argtypes = [C.POINTER(AADHeaderInfo), C.c_uint32]
+    lib.AADFormat_DecodeWorkBounded.restype = C.c_int
+    for bits in (4, 3, 2):
+        h = AADHeaderInfo(format_version=4, codec_version=18, num_channels=2, num_samples=1, sampling_rate=48000,
+                          bits_per_sample=bits, block_size=1024, num_samples_per_block=0xFFFFFFF0, ch_process_method=0)
+        assert lib.AADFormat_DecodeWorkBounded(C.byref(h), 3000) == 1          # the block is cut at num_samples
+        assert lib.AADFormat_DecodeWorkBounded(C.byref(h), 0x7FFFFFFF) == 1
+        assert lib.AADFormat_DecodeWorkBounded(C.byref(h), 0x80000000) == 0
+        assert lib.AADFormat_DecodeWorkBounded(C.byref(h), 0xFFFFFFF8) == 0     # the wrap case of the 3-bit loop
+        h.num_samples_per_block = 992
+        assert lib.AADFormat_DecodeWorkBounded(C.byref(h), 0xFFFFFFFF) == 1     # many ordinary blocks are fine
+
+
+def test_context_option_needs_a_context(lib):
+    assert lib.AADHip_ContextSetOption(None, 0, 1) == R.INVALID_ARGUMENT
+
+
+def test_native_corpus_generator_equals_numpy_specification():
+    """aad_amd/csrc/aad_synth.c against aad_amd/synth.py's numpy form, every kind, odd shapes."""
+    from aad_amd.synth import _native_generator, synth_pcm
+    assert _native_generator(), "libaad_hip.so lacks AADSynth_Generate"
+    for kind in ("music", "noise", "nyquist"):
+        for streams, n, ch, seed, first in ((3, 500, 2, 1234, 0), (2, 333, 8, 77, 5), (1, 1, 1, 0, 0), (5, 64, 3, 99, 1000)):
+            a = synth_pcm(streams, n, ch, seed=seed, kind=kind, first_stream=first, native=False)
+            b = synth_pcm(streams, n, ch, seed=seed, kind=kind, first_stream=first, native=True)
+            assert np.array_equal(a, b), (kind, streams, n, ch)
+    assert synth_pcm(0, 10, 2).shape == (0, 10, 2)
 
 
 def test_encoded_size_matches_formula(lib):

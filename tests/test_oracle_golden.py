@@ -74,6 +74,57 @@ def test_eight_channel_equals_mono_lanes():
                 assert sha256(extract_channel_as_mono(aad8, c, 128)) == want["aad_sha256"]
 
 
+@pytest.mark.parametrize("corpus", MANIFEST["corpora"], ids=lambda c: c["name"])
+def test_corpus_hashes(corpus):
+    """The BASELINE corpora and the long in-lane block chains (1 x 1000 blocks with and without the
+    trial search, 1000 x 16 blocks, multi-block mono 2-/3-bit) against the compiled reference's hashes."""
+    import hashlib
+    pcm = synth_pcm(corpus["streams"], corpus["samples"], corpus["channels"], seed=corpus["seed"])
+    assert sha256(pcm.tobytes()) == corpus["pcm_sha256"], "synthetic corpus generator drifted"
+    stride = ob.encoded_size(corpus["samples"], corpus["channels"], corpus["bits"], corpus["max_block_size"])
+    assert stride == corpus["image_bytes"]
+    img = np.zeros((corpus["streams"], stride), dtype=np.uint8)
+    assert ob.lib().aado_encode_batch(pcm.ctypes.data, corpus["streams"], corpus["samples"], corpus["channels"], 48000,
+                                      corpus["bits"], corpus["max_block_size"], 0, corpus["trials"], img.ctypes.data, stride) == 0
+    assert hashlib.sha256(img.tobytes()).hexdigest() == corpus["aad_concat_sha256"]
+    dec = np.zeros_like(pcm)
+    assert ob.lib().aado_decode_batch(img.ctypes.data, corpus["streams"], stride, stride, dec.ctypes.data, corpus["samples"]) == 0
+    assert hashlib.sha256(dec.tobytes()).hexdigest() == corpus["decoded_concat_sha256"]
+
+
+def test_file_corpus_prefix_hashes_are_consistent():
+    """BASELINE config 5's 10 000-file corpus is pinned by prefix hashes (1250 / 2500 / 5000 / 10000 files,
+    what 1 / 2 / 4 / 8 ranks x 1250 files gather); its first 1250 files ARE the 1250-file corpus above,
+    and the oracle reproduces the 2500-file prefix."""
+    import hashlib
+    fc = MANIFEST["file_corpora"][0]
+    shard = [c for c in MANIFEST["corpora"] if c["name"] == "cfg5_stereo4_1250x10blk_t0"][0]
+    assert fc["aad_prefix_sha256"]["1250"] == shard["aad_concat_sha256"]
+    pcm = synth_pcm(2500, fc["samples"], 2, seed=fc["seed"])
+    img = np.zeros((2500, fc["image_bytes"]), dtype=np.uint8)
+    assert ob.lib().aado_encode_batch(pcm.ctypes.data, 2500, fc["samples"], 2, 48000, 4, 1024, 0, 0, img.ctypes.data, fc["image_bytes"]) == 0
+    assert hashlib.sha256(img.tobytes()).hexdigest() == fc["aad_prefix_sha256"]["2500"]
+
+
+@pytest.mark.parametrize("corpus", MANIFEST["eight_channel_corpora"], ids=lambda c: c["name"])
+def test_eight_channel_corpus_hashes(corpus):
+    """BASELINE config 4 at full size (10 000 eight-channel one-block segments, 3- and 2-bit): every
+    (segment, channel) re-framed as a mono image equals the reference's mono encode of that channel."""
+    import hashlib
+    from aad_amd.reframe import channels_as_mono_images
+    pcm = synth_pcm(corpus["streams"], corpus["samples"], 8, seed=corpus["seed"])
+    assert sha256(pcm.tobytes()) == corpus["pcm_sha256"]
+    stride = ob.encoded_size(corpus["samples"], 8, corpus["bits"], 1024)
+    img = np.zeros((corpus["streams"], stride), dtype=np.uint8)
+    assert ob.lib().aado_encode_batch(pcm.ctypes.data, corpus["streams"], corpus["samples"], 8, 48000, corpus["bits"], 1024, 0, 0,
+                                      img.ctypes.data, stride) == 0
+    mono = channels_as_mono_images(img, 8, corpus["bits"], corpus["block_size"], corpus["mono_block_size"])
+    assert mono.shape[2] == corpus["mono_image_bytes"]
+    assert hashlib.sha256(np.ascontiguousarray(mono).tobytes()).hexdigest() == corpus["mono_images_concat_sha256"]
+    # the vectorised re-framing agrees with the byte-by-byte one
+    assert bytes(mono[3, 5]) == extract_channel_as_mono(bytes(img[3]), 5, 128)
+
+
 def extract_channel_as_mono(aad, c, mono_max_block_size):
     """Re-frame channel c of a multi-channel image as the mono image with the same samples/block."""
     import math

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE in one, WRITE_SIZE in the other; the TCC block
-cannot hold both) of `bench.py` into profiles/r01_hbm_traffic.json: HBM bytes per launch of the
+cannot hold both) of `bench.py` into profiles/rNN_hbm_traffic.json: HBM bytes per launch of the
 encode and decode kernels, corrected as /opt/skills/guides/MI355X_MICROARCH.md section HBM says
 (FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide
 coalesced stream, so the read side is reported both raw and doubled - these kernels read 16-B
@@ -41,8 +41,11 @@ def main():
             kernels[k] = {"FETCH_SIZE_KiB": round(fetch[k], 1), "WRITE_SIZE_KiB": round(write[k], 1),
                           "read_bytes_raw": int(rd_raw), "read_bytes_doubled": int(2 * rd_raw), "write_bytes": int(wr),
                           "hbm_bytes_per_launch": int(rd_raw + wr), "hbm_bytes_per_launch_upper": int(2 * rd_raw + wr)}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_digest  # the stamp bench.py checks before it quotes these numbers
     json.dump({"streams": int(streams), "samples_per_channel": int(samples), "kernels": kernels,
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py"}, open(out, "w"), indent=1)
+               "kernel_source_sha256": kernel_source_digest(),
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --no-extras"}, open(out, "w"), indent=1)
     print(json.dumps(kernels, indent=1))
 
 
