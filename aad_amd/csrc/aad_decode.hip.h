@@ -131,7 +131,7 @@ __device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, DecodeCarry &C,
     constexpr int j = decltype(jc)::value;
     const int32_t qd = mad_i24((int32_t)step0, (int32_t)t0.x, (int32_t)t0.y) >> (BITS - 1);
     const int32_t yy = clip16(qd + p);
-    lms_and_shift<true>(L, qd, yy);
+    lms_and_shift<kShiftSelect>(L, qd, yy);
     y[j] = finish(yy);
     uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
     pin(s);

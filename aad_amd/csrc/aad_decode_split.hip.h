@@ -398,7 +398,7 @@ __device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint6
       if ((uint32_t)j < rem) {
         const int32_t qd = last.get(j);
         const int32_t yy = clip16(qd + p);
-        lms_and_shift<true>(L, qd, yy);
+        lms_and_shift<kShiftSelect>(L, qd, yy);
         p = predict(L);
         const int32_t yo = finish(yy);
         if (writer) dst[(uint64_t)(kTaps + full * kChunk + j) * ch] = (int16_t)yo;

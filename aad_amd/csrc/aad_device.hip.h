@@ -316,31 +316,62 @@ struct QuadLane {
   bool tap0;
 };
 
+/* Two lane layouts of a quad.  Tap-minor (decoders): the four taps of a recurrence are four ADJACENT
+ * lanes, cross-tap traffic is quad_perm DPP.  Tap-major (encoder): within every row of sixteen lanes
+ * lane = 4 * tap + r, i.e. bank b of the row holds tap b of four recurrences r = 0..3 - cross-tap
+ * traffic is row_ror / row_shr by 4, and because a DPP write can be switched off per BANK, the
+ * history shift "every tap takes the next-newer tap's sample, tap 0 keeps the new one" is ONE
+ * instruction (see kShiftBankMask).  The channels of a stereo stream are then adjacent lanes. */
+constexpr int kDppRowShr4 = 0x114, kDppRowRor4 = 0x124, kDppRowRor8 = 0x128;
+template <bool TM> __device__ __forceinline__ uint32_t quad_tap() { return TM ? (threadIdx.x >> 2) & 3u : threadIdx.x & 3u; }
+/* index of the lane's recurrence among the 16 of its wave */
+template <bool TM> __device__ __forceinline__ uint32_t quad_slot()
+{
+  const uint32_t l = threadIdx.x & 63u;
+  return TM ? ((l >> 4) << 2) | (l & 3u) : l >> 2;
+}
+/* lane (within the wave) of tap t of recurrence slot q */
+template <bool TM> __device__ __forceinline__ uint32_t quad_lane_of(uint32_t q, uint32_t t)
+{
+  return TM ? ((q >> 2) << 4) | (t << 2) | (q & 3u) : (q << 2) | t;
+}
+
+template <bool TM = false>
 __device__ __forceinline__ int32_t predict(const QuadLane &Q)
 {
   uint32_t s = (uint32_t)Q.h * (uint32_t)Q.w + Q.round;
-  s += quad_dpp<0xB1>(s); /* quad_perm [1,0,3,2] */
-  s += quad_dpp<0x4E>(s); /* quad_perm [2,3,0,1] */
+  s += quad_dpp<TM ? kDppRowRor4 : 0xB1>(s); /* quad_perm [1,0,3,2] */
+  s += quad_dpp<TM ? kDppRowRor8 : 0x4E>(s); /* quad_perm [2,3,0,1] */
   return (int32_t)s >> 15;
 }
 __device__ __forceinline__ void lms_first(QuadLane &Q, int32_t qd) { Q.w += mad_i24(qd, Q.h, 16384) >> 18; }
-/* History shift.  SELECT: one v_mov_b32_dpp + v_cndmask on a lane mask the compiler keeps in VCC
- * (decoder: shortest path from the new sample to the next product).  Otherwise a bit-select on a
- * per-lane VGPR mask (v_and_b32_dpp + v_and_or_b32): the encoder bodies have no spare VCC, there
- * the select's mask ended up in an SGPR pair in some instantiations (the trial-search kernels),
- * and those ran every chunk ~24 % slower than the very same code with the mask in VCC. */
-template <bool SELECT = false>
+/* History shift: every tap takes the next-newer tap's sample, tap 0 the reconstructed one.
+ *   kShiftBankMask  tap-major layout only, ONE instruction: v_mov_b32_dpp row_shr:4 with bank_mask
+ *                   0xE - the DPP write is switched off for bank 0 of every row (= the tap-0 lanes),
+ *                   which keeps what the destination register held before: y.  (y must not be needed
+ *                   afterwards, or the compiler pays a copy; the DPP may not follow the write of y by
+ *                   fewer than two instructions - the LMS update sits in between.)
+ *   kShiftSelect    v_mov_b32_dpp + v_cndmask on a lane mask the compiler keeps in VCC.
+ *   kShiftBitSelect v_and_b32_dpp + v_and_or_b32 on a per-lane VGPR mask: for bodies with no spare
+ *                   VCC, where the select's mask ended up in an SGPR pair in some instantiations
+ *                   (the trial-search kernels) and those ran every chunk ~24 % slower. */
+enum { kShiftBitSelect = 0, kShiftSelect = 1, kShiftBankMask = 2 };
+template <int MODE = kShiftBitSelect>
 __device__ __forceinline__ void lms_rest_and_shift(QuadLane &Q, int32_t, int32_t y)
 {
+  if (MODE == kShiftBankMask) {
+    Q.h = __builtin_amdgcn_update_dpp(y, Q.h, kDppRowShr4, 0xF, 0xE, false);
+    return;
+  }
   const uint32_t up = quad_dpp<0x90>((uint32_t)Q.h); /* quad_perm [0,0,1,2]: the next-older tap's sample */
-  if (SELECT) Q.h = Q.tap0 ? y : (int32_t)up;
+  if (MODE == kShiftSelect) Q.h = Q.tap0 ? y : (int32_t)up;
   else Q.h = (int32_t)(((uint32_t)y & Q.newest) | (up & ~Q.newest));
 }
-template <bool SELECT = false>
+template <int MODE = kShiftBitSelect>
 __device__ __forceinline__ void lms_and_shift(QuadLane &Q, int32_t qd, int32_t y)
 {
   lms_first(Q, qd);
-  lms_rest_and_shift<SELECT>(Q, qd, y);
+  lms_rest_and_shift<MODE>(Q, qd, y);
 }
 __device__ __forceinline__ void pin_weights(QuadLane &Q) { pin(Q.w); }
 
@@ -358,9 +389,23 @@ __device__ __forceinline__ QuadLane to_quad(const Lane &L, uint32_t tap)
   if (BITMASK) pin(Q.newest); /* opaque: keeps the bit-select from being turned back into a v_cndmask */
   return Q;
 }
+template <bool TM = false>
 __device__ __forceinline__ Lane from_quad(const QuadLane &Q)
 {
   Lane L;
+  if (TM) { /* block boundaries only: eight wave shuffles, one wait */
+    const uint32_t q = quad_slot<true>();
+    L.w0 = __shfl(Q.w, (int)quad_lane_of<true>(q, 0), 64);
+    L.w1 = __shfl(Q.w, (int)quad_lane_of<true>(q, 1), 64);
+    L.w2 = __shfl(Q.w, (int)quad_lane_of<true>(q, 2), 64);
+    L.w3 = __shfl(Q.w, (int)quad_lane_of<true>(q, 3), 64);
+    L.h0 = __shfl(Q.h, (int)quad_lane_of<true>(q, 0), 64);
+    L.h1 = __shfl(Q.h, (int)quad_lane_of<true>(q, 1), 64);
+    L.h2 = __shfl(Q.h, (int)quad_lane_of<true>(q, 2), 64);
+    L.h3 = __shfl(Q.h, (int)quad_lane_of<true>(q, 3), 64);
+    L.idxb = Q.idxb;
+    return L;
+  }
   L.w0 = (int32_t)quad_dpp<0x00>((uint32_t)Q.w);
   L.w1 = (int32_t)quad_dpp<0x55>((uint32_t)Q.w);
   L.w2 = (int32_t)quad_dpp<0xAA>((uint32_t)Q.w);
@@ -378,7 +423,8 @@ __device__ __forceinline__ Lane from_quad(const QuadLane &Q)
 /* v_perm_b32: selector bytes 0-3 pick from `lo`, 4-7 from `hi`, 0x0c yields 0x00 */
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
-/* value of the neighbouring lane (lane ^ 1): the other channel of a stereo pair */
+/* value of the lane that holds the other channel of a stereo pair.  QUAD = tap-minor quad layout
+ * (the pair is four lanes away); dense mapping and tap-major quad layout: the neighbouring lane. */
 template <bool QUAD>
 __device__ __forceinline__ uint32_t pair_swap(uint32_t v, uint32_t c)
 {

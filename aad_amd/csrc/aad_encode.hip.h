@@ -11,6 +11,9 @@
 
 namespace aad {
 
+/* the encoder's quad kernels use the tap-major lane layout (aad_device.hip.h) */
+constexpr bool kEncTM = true;
+
 /* Q4 step-index delta of a magnitude code as arithmetic (the constants of reference
  * src/aad_tables.c:8-45): 4-bit {-18,-17,-14,16,32,64,128,256}, 3-bit {-16,-15,32,128},
  * 2-bit {-14,40}.  Five instructions instead of an LDS lookup: used where that lookup would sit
@@ -19,9 +22,11 @@ template <int BITS>
 __device__ __forceinline__ int32_t index_delta_arith(uint32_t mag)
 {
   if (BITS == 4) {
-    /* 2 << mag, minus {20, 21, 22, 0, 0, 0, 0, 0}[mag] picked by one v_perm_b32 byte lookup
-     * (selector bytes 1-3 = 0x0c give zero): no compare/select pair, no SGPR hazard */
-    const uint32_t corr = __builtin_amdgcn_perm(0u, 0x00161514u, mag | 0x0c0c0c00u);
+    /* 2 << mag, minus {20, 21, 22, 0, 0, 0, 0, 0}[mag] picked by one v_perm_b32 byte lookup:
+     * no compare/select pair, no SGPR hazard */
+    /* selector = mag as it is: its upper bytes (zero) replicate table byte 0 into bytes 1-3 of the
+     * result, which the subtract then ignores by reading byte 0 only (v_sub_u32_sdwa) */
+    const uint32_t corr = __builtin_amdgcn_perm(0u, 0x00161514u, mag) & 0xFFu;
     return (int32_t)(2u << mag) - (int32_t)corr;
   } else if (BITS == 3) {
     return mag < 2 ? (int32_t)mag - 16 : (int32_t)(2u << (2u * mag));
@@ -40,7 +45,8 @@ __device__ __forceinline__ uint32_t encode_step(S &L, int32_t x, const char *lds
   const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
   const float hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
   const float hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
-  const int32_t p = predict(L);
+  int32_t p;
+  if constexpr (std::is_same_v<S, QuadLane>) p = predict<kEncTM>(L); else p = predict(L);
   const int32_t d = x - p;
   const int32_t m = d >> 31; /* 0 or -1 */
   /* min((|d| << (BITS-2)) / step, magmax) == min(trunc(fma(|d|, 2^(BITS-1)*hr, hr)), magmax), hr = fl32(0.5/step) */
@@ -51,7 +57,8 @@ __device__ __forceinline__ uint32_t encode_step(S &L, int32_t x, const char *lds
   /* m21 = 2*mag + 1 addresses the int16 delta table: byte offset 2*mag = m21 - 1 */
   const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDeltaOff - 1) + m21);
   L.idxb = clamp_idx(L.idxb + delta);
-  lms_and_shift(L, qd, clip16(qd + p));
+  if constexpr (std::is_same_v<S, QuadLane>) lms_and_shift<kEncTM ? kShiftBankMask : kShiftBitSelect>(L, qd, clip16(qd + p));
+  else lms_and_shift(L, qd, clip16(qd + p));
   return mag | ((uint32_t)m & Pack<BITS>::kSign);
 }
 
@@ -157,7 +164,7 @@ template <int BITS>
 __device__ __forceinline__ void encode_prime_quad(QuadLane &L, EncodeCarry &C, int32_t x0, const char *lds)
 {
   C.e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
-  C.p = predict(L);
+  C.p = predict<kEncTM>(L);
   C.d = x0 - C.p;
   C.m = C.d >> 31;
   C.f = (float)C.d;
@@ -165,17 +172,23 @@ __device__ __forceinline__ void encode_prime_quad(QuadLane &L, EncodeCarry &C, i
 
 /* x: this chunk's 16 samples, xn0: the first sample of the next chunk (the pipeline is carried
  * from chunk to chunk like the decoder's, see DecodeCarry) */
-/* PACKED: x holds the chunk as eight dwords of two int16 samples each (and xn0 the next chunk's
- * first such dword) instead of sixteen sign-extended values */
-template <int BITS, bool EMIT, bool PACKED = false>
+/* How the chunk's samples sit in x (and the next chunk's first one in xn0):
+ *   kWide    sixteen sign-extended values (M/S: the transform needs them widened)
+ *   kPairs   eight dwords of two int16 samples each - mono PCM exactly as it was loaded
+ *   kFrames  sixteen dwords whose LOW half is this lane's sample - stereo PCM exactly as it was
+ *            loaded, the channel-1 lane having loaded from two bytes further on
+ * The subtract reads the halves directly (v_sub_u32_sdwa): no per-sample extraction. */
+enum { kWide = 0, kPairs = 1, kFrames = 2 };
+template <int BITS, bool EMIT, int FORMAT = kWide>
 __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C, const int32_t *x, int32_t xn0,
                                                     const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq)
 {
   auto sample = [&](int k) -> int32_t { /* sample k of this chunk (k = 16: first of the next), k compile-time */
-    if (PACKED) {
+    if (FORMAT == kPairs) {
       const int32_t word = k < kChunk ? x[k >> 1] : xn0;
       return (k & 1) ? word >> 16 : (int32_t)(int16_t)word;
     }
+    if (FORMAT == kFrames) return (int32_t)(int16_t)(k < kChunk ? x[k] : xn0);
     return k < kChunk ? x[k] : xn0;
   };
   u32x3 e = C.e;
@@ -197,7 +210,7 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     const int32_t q = (int32_t)__umulhi(step2_j, m21s);
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
-    lms_and_shift(L, qd, y);
+    lms_and_shift<kEncTM ? kShiftBankMask : kShiftBitSelect>(L, qd, y);
     /* prediction of the next sample, with the two instructions that pack this sample's code
      * placed in the wait states its DPP adds need (see decode_chunk16_quad) */
     uint32_t s = (uint32_t)L.h * (uint32_t)L.w + L.round;
@@ -210,7 +223,7 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
       sqw = (uint32_t)qd * (uint32_t)qd;
       pin(sqw);
     }
-    s += quad_dpp<0xB1>(s);
+    s += quad_dpp<kEncTM ? kDppRowRor4 : 0xB1>(s);
     pin(s);
     if (EMIT) {
       uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
@@ -219,13 +232,22 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     } else {
       sq += (int64_t)(int32_t)sqw;
     }
-    s += quad_dpp<0x4E>(s);
+    /* The wait for the step record asked for in A goes HERE.  It has to be somewhere before the next
+     * sample's quantiser, and in this slot it doubles as the second wait state the DPP add below
+     * needs (where the compiler put it, in front of the quantiser, it cost a slot of its own and
+     * this gap was padded with an s_nop).  Not earlier: in the first gap, 13 instructions after the
+     * lookup was issued, the record is still on its way and the wave stalls (measured: 72.6 us per
+     * launch of the bench batch with the wait in the first gap, 70.4 in front of the quantiser,
+     * 68.6 here). */
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */
+    s += quad_dpp<kEncTM ? kDppRowRor8 : 0x4E>(s);
     p = (int32_t)s >> 15;
     d = sample(j + 1) - p;
-    m = d >> 31;
+    /* only ONE of the two is pinned behind the scheduling barrier: with both, the hazard recogniser
+     * put an s_nop in front of the quantiser that opens the next sample */
     f = (float)d;
+    m = d >> 31;
     pin(m);
-    pin(f);
     if (j + 1 == kChunk) qd_out = qd;
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -261,6 +283,7 @@ template <bool MS>
 struct SampleSource {
   const int16_t *x;
   uint32_t ch, c;
+  uint32_t total; /* frames in the stream */
   __device__ __forceinline__ int32_t at(uint64_t i) const
   {
     if (MS) {
@@ -434,14 +457,63 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
     constexpr uint32_t kOutStride = Pack<BITS>::kChunkBytes;
     CS next;
     for (auto &v : next.d) v = 0;
-    if (full) next.load(xp, ch, c);
-    next.touch();
-    if constexpr (QUAD) {
-      /* pipeline carried across chunks: chunk k+1's samples are extracted one chunk early.
-       * Without M/S they stay packed two to a dword (kN = 8 registers per chunk); the M/S
-       * transform needs them widened (kN = 16). */
-      constexpr bool PK = !MS;
-      constexpr int kN = PK ? kChunk / 2 : kChunk;
+    if constexpr (!(QUAD && !MS)) {
+      if (full) next.load(xp, ch, c);
+      next.touch();
+    }
+    if constexpr (QUAD && !MS) {
+      /* Without M/S the loaded dwords ARE what the chunk body reads (kPairs / kFrames above), so
+       * three register sets rotate (the loop is unrolled by three, as in the split decoder): chunk k
+       * is consumed from one, chunk k+1 - whose first sample the last step of chunk k looks ahead
+       * to - sits in the second, chunk k+2 is in flight into the third.  No extraction, no copies;
+       * the compiler's own vmcnt waits land where a set is first read, two chunks after its loads
+       * were issued (loads older than the code stores in between: nothing waits for a store).
+       * Stereo: the channel-1 lane loads from one int16 further on, so that its sample is the low
+       * half of every dword as well; the last full chunk of a stream that ends on a chunk boundary
+       * is left to the tail loop - its channel-1 load would read two bytes past the stream. */
+      constexpr int FMT = CHF == 1 ? kPairs : kFrames;
+      struct Raw { /* one chunk as loaded: 32 (mono) / 64 (stereo) bytes */
+        uint32_t d[CHF == 1 ? 8 : 16];
+        __device__ __forceinline__ void load(const int16_t *x)
+        {
+#pragma unroll
+          for (int k = 0; k < (CHF == 1 ? 2 : 4); k++) {
+            const u32x4 a = reinterpret_cast<const U32x4 *>(x + 8 * k)->v;
+            d[4 * k] = a.x; d[4 * k + 1] = a.y; d[4 * k + 2] = a.z; d[4 * k + 3] = a.w;
+          }
+        }
+      };
+      uint32_t chunks = full;
+      if (CHF == 2 && chunks && chunks * kChunk == coded && first + n >= (uint64_t)src.total) chunks--;
+      const int16_t *rp = xp + (CHF == 2 ? c : 0);
+      Raw b0, b1, b2;
+      for (auto &v : b0.d) v = 0;
+      for (auto &v : b1.d) v = 0;
+      for (auto &v : b2.d) v = 0;
+      EncodeCarry C;
+      if (chunks) {
+        b0.load(rp);
+        if (chunks > 1) rp += (uint64_t)kChunk * ch;
+        b1.load(rp);
+        encode_prime_quad<BITS>(L, C, (int32_t)(int16_t)b0.d[0], lds); /* both formats: sample 0 is the low half of dword 0 */
+      }
+      auto one = [&](uint32_t k, const Raw &cur, const Raw &ahead, Raw &incoming) {
+        if (k + 2 < chunks) rp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
+        incoming.load(rp);
+        uint32_t w[2] = {0, 0};
+        encode_chunk16_quad<BITS, EMIT, FMT>(L, C, reinterpret_cast<const int32_t *>(cur.d), (int32_t)ahead.d[0], lds, w, last_qd, sq);
+        if (EMIT && writer) store_chunk_codes<BITS, CHF, QUAD && !kEncTM>(body + (uint64_t)k * kOutStride * ch, w, c);
+      };
+      for (uint32_t k = 0; k < chunks; k += 3) {
+        one(k, b0, b1, b2);
+        if (k + 1 < chunks) one(k + 1, b1, b2, b0);
+        if (k + 2 < chunks) one(k + 2, b2, b0, b1);
+      }
+      done = chunks * kChunk;
+    } else if constexpr (QUAD) {
+      /* M/S: the transform needs the samples widened (kWide); they are extracted one chunk early */
+      constexpr bool PK = false;
+      constexpr int kN = kChunk;
       const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
       auto extract = [&](int32_t(&dst)[kN]) {
 #pragma unroll
@@ -465,15 +537,16 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         if (k + 2 < full) xp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
         next.load(xp, ch, c);
         uint32_t w[2] = {0, 0};
-        encode_chunk16_quad<BITS, EMIT, PK>(L, C, cur, ahead[0], lds, w, last_qd, sq);
+        encode_chunk16_quad<BITS, EMIT, kWide>(L, C, cur, ahead[0], lds, w, last_qd, sq);
         next.touch();
         extract(cur);
-        if (EMIT && writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD>(body + (uint64_t)k * kOutStride * ch, w, c);
+        if (EMIT && writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD && !kEncTM>(body + (uint64_t)k * kOutStride * ch, w, c);
       };
       for (uint32_t k = 0; k < full; k += 2) {
         one(k, x, xn);
         if (k + 1 < full) one(k + 1, xn, x);
       }
+      done = full * kChunk;
     } else {
       /* mono / stereo without M/S: the samples stay packed two to a dword (see encode_chunk16) */
       constexpr bool PK = CHF != 0 && !MS;
@@ -505,8 +578,8 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
           }
         }
       }
+      done = full * kChunk;
     }
-    done = full * kChunk;
   }
 
   if (EMIT) { /* tail units: samples past n are zero padding - reference :592-593 */
@@ -597,7 +670,8 @@ __device__ __forceinline__ void search_best_lane_dual(S &L, const SampleSource<M
 {
   const bool have_prev = first >= spb;
   const uint32_t chain_passes = trials * (have_prev ? 2u : 1u);
-  const int chain_lane = (int)((threadIdx.x & 63u) - role * 4u * (CHF ? CHF : 1)); /* role 0's lane of the same tap */
+  constexpr uint32_t kRoleStride = (kEncTM ? 1u : 4u) * (CHF ? CHF : 1); /* lanes between the two roles' quads of a channel */
+  const int chain_lane = (int)((threadIdx.x & 63u) - role * kRoleStride); /* role 0's lane of the same tap */
   S best = L, run = L;
   double best_rmse = 0.0;
   for (uint32_t p = 0; p < chain_passes; p++) {
@@ -611,7 +685,7 @@ __device__ __forceinline__ void search_best_lane_dual(S &L, const SampleSource<M
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
     if (p == 0) {
       /* the probe's figure goes to both roles; role 1 takes over role 0's chain state and result */
-      const double probe = __shfl(r, chain_lane + (int)(4u * (CHF ? CHF : 1)), 64);
+      const double probe = __shfl(r, chain_lane + (int)kRoleStride, 64);
       best_rmse = role == 0 ? probe : r;
       r = __shfl(r, chain_lane, 64);
       run.w = __shfl(run.w, chain_lane, 64);
@@ -642,18 +716,20 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 
   const uint32_t ch = CHF ? CHF : a.channels;
   const uint64_t thread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  /* dual: with trials on the quad mapping every stream owns 2 x CHF quads, laid out
-   * [role 0: ch 0 .. CHF-1][role 1: ch 0 .. CHF-1] so that a stereo pair stays 4 lanes apart */
+  /* dual: with trials on the quad mapping every stream owns 2 x CHF recurrence slots, laid out
+   * [role 0: ch 0 .. CHF-1][role 1: ch 0 .. CHF-1] so that a stereo pair stays adjacent */
   constexpr uint32_t kQuadsPerStream = DUAL ? 2u * (CHF ? CHF : 1) : 1u;
-  const uint32_t role = DUAL ? (uint32_t)((thread >> 2) % kQuadsPerStream) / (CHF ? CHF : 1) : 0u;
-  const uint64_t lane = DUAL ? (thread >> 2) / kQuadsPerStream * (CHF ? CHF : 1) + (thread >> 2) % (CHF ? CHF : 1)
-                             : (QUAD ? thread >> 2 : thread); /* index of the (stream, channel) recurrence */
-  const uint32_t tap = QUAD ? threadIdx.x & 3u : 0u;
+  /* quad: sixteen recurrence slots per wave, four lanes each (lane layout: aad_device.hip.h) */
+  const uint64_t slot = QUAD ? (thread >> 6) * 16u + quad_slot<kEncTM>() : thread;
+  const uint32_t role = DUAL ? (uint32_t)(slot % kQuadsPerStream) / (CHF ? CHF : 1) : 0u;
+  const uint64_t lane = DUAL ? slot / kQuadsPerStream * (CHF ? CHF : 1) + slot % (CHF ? CHF : 1)
+                             : slot; /* index of the (stream, channel) recurrence */
+  const uint32_t tap = QUAD ? quad_tap<kEncTM>() : 0u;
   const bool writer = tap == 0 && role == 0;         /* quad: all four lanes hold the codes, one stores them */
   if (lane >= (uint64_t)a.num_streams * ch) return; /* whole quads / stereo pairs / role groups leave together */
   const uint32_t s = (uint32_t)(lane / ch), c = (uint32_t)(lane % ch);
   const StreamDesc sd = a.uni.enabled ? uniform_stream(a.uni, s) : a.streams[s];
-  const SampleSource<MS> src = {a.pcm + sd.pcm_offset, ch, c};
+  const SampleSource<MS> src = {a.pcm + sd.pcm_offset, ch, c, sd.num_samples};
   uint8_t *out = a.data + sd.data_offset;
   const uint32_t total = sd.num_samples, spb = a.samples_per_block;
 
@@ -688,7 +764,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
       if constexpr (QUAD) L = to_quad(F, tap); else L = F;
       if constexpr (DUAL) search_best_lane_dual<BITS, CHF, MS>(L, src, first, n, spb, a.trials, ch, c, tap, role, lds);
       else search_best_lane<BITS, CHF, MS, QUAD>(L, src, first, n, spb, a.trials, ch, c, tap, lds);
-      if constexpr (QUAD) F = from_quad(L); else F = L;
+      if constexpr (QUAD) F = from_quad<kEncTM>(L); else F = L;
     }
     seed_history(F, src, first, n);
     write_block_header(F, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh, writer);
@@ -698,7 +774,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
     /* dual: role 1 runs the encode pass as well (it holds the same state; only role 0 stores),
      * which also leaves it with the right state for the next block */
     (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd);
-    if constexpr (QUAD) F = from_quad(L); else F = L;
+    if constexpr (QUAD) F = from_quad<kEncTM>(L); else F = L;
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   }
 
