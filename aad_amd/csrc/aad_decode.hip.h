@@ -18,10 +18,10 @@ template <int BITS, typename S>
 __device__ __forceinline__ int32_t decode_step(S &L, uint32_t code, const char *lds)
 {
   const uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
-  const u32x3 t = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + ((code & ((1u << BITS) - 1u)) << 4));
-  const int32_t qd = mad_i24((int32_t)step, (int32_t)t.x, (int32_t)t.y) >> (BITS - 1);
+  const u32x2 t = code_record(lds, (code & ((1u << BITS) - 1u)) << kLdsCodeShift);
+  const int32_t qd = record_dequantise<BITS>(step, t);
   const int32_t y = clip16(qd + predict(L));
-  L.idxb = clamp_idx(L.idxb + (int32_t)t.z);
+  L.idxb = clamp_idx(L.idxb + record_delta(t));
   lms_and_shift(L, qd, y);
   return y;
 }
@@ -34,35 +34,37 @@ __device__ __forceinline__ int32_t decode_step(S &L, uint32_t code, const char *
  *   A  step index of the next sample; start its step lookup and the record lookup of sample j+2
  *   B  dequantise (mad + shift), reconstruct, LMS, history shift, predict the next sample
  */
-template <int BITS, typename S, typename Finish>
+template <int BITS, int N = kChunk, typename S, typename Finish>
 __device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const char *lds, int32_t *y, Finish finish)
 {
+  static_assert(N >= 2 && N <= kChunk, "the first N samples of a chunk's code words");
   constexpr int cpw = Pack<BITS>::kCodesPerWord;
-  auto code_addr = [&](int j) -> uint32_t { /* (code << 4) for sample j, j compile-time after unrolling */
+  auto code_addr = [&](int j) -> uint32_t { /* (code << kLdsCodeShift) for sample j, j compile-time after unrolling */
+    constexpr int sh = kLdsCodeShift;
     const int pos = Pack<BITS>::pos(j % cpw);
     const uint32_t word = w[j / cpw];
-    return (pos >= 4 ? word >> (pos >= 4 ? pos - 4 : 0) : word << (4 - pos)) & (((1u << BITS) - 1u) << 4);
+    return (pos >= sh ? word >> (pos >= sh ? pos - sh : 0) : word << (sh - pos)) & (((1u << BITS) - 1u) << sh);
   };
   uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
   /* per-code records two samples ahead: they depend on nothing but the code bits */
-  u32x3 t0 = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(0));
-  u32x3 t1 = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(1));
+  u32x2 t0 = code_record(lds, code_addr(0));
+  u32x2 t1 = code_record(lds, code_addr(1));
   int32_t p = predict(L);
-  static_for<0, kChunk>([&](auto jc) {
+  static_for<0, N>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     /* A */
     const uint32_t step_j = step;
-    const u32x3 t_j = t0;
+    const u32x2 t_j = t0;
     t0 = t1;
-    L.idxb = clamp_idx(L.idxb + (int32_t)t_j.z);
-    if (j + 1 < kChunk) step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
-    if (j + 2 < kChunk) t1 = *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + code_addr(j + 2 < kChunk ? j + 2 : j));
+    L.idxb = clamp_idx(L.idxb + record_delta(t_j));
+    if (j + 1 < N) step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
+    if (j + 2 < N) t1 = code_record(lds, code_addr(j + 2 < N ? j + 2 : j));
     __builtin_amdgcn_sched_barrier(0);
     /* B */
-    const int32_t qd = mad_i24((int32_t)step_j, (int32_t)t_j.x, (int32_t)t_j.y) >> (BITS - 1);
+    const int32_t qd = record_dequantise<BITS>(step_j, t_j);
     const int32_t yy = clip16(qd + p);
     lms_and_shift(L, qd, yy);
-    if (j + 1 < kChunk) {
+    if (j + 1 < N) {
       p = predict(L);
       pin(p);
     } else {
@@ -89,7 +91,7 @@ __device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const ch
  */
 struct DecodeCarry {
   uint32_t step0, step1; /* step sizes of samples j, j+1 */
-  u32x3 t0, t1, t2;      /* per-code records of samples j, j+1, j+2 */
+  u32x2 t0, t1, t2;      /* per-code records of samples j, j+1, j+2 */
   int32_t p;             /* prediction for sample j */
   int32_t idx_next;      /* step index (biased) of the first sample after the chunk just finished */
 };
@@ -98,21 +100,22 @@ template <int BITS>
 __device__ __forceinline__ uint32_t chunk_code_addr(const uint32_t *w, const uint32_t *wn, int j)
 {
   constexpr int cpw = Pack<BITS>::kCodesPerWord;
+  constexpr int sh = kLdsCodeShift;
   const uint32_t word = j < kChunk ? w[j / cpw] : wn[(j - kChunk) / cpw];
   const int pos = Pack<BITS>::pos((j % kChunk) % cpw);
-  return (pos >= 4 ? word >> (pos >= 4 ? pos - 4 : 0) : word << (4 - pos)) & (((1u << BITS) - 1u) << 4);
+  return (pos >= sh ? word >> (pos >= sh ? pos - sh : 0) : word << (sh - pos)) & (((1u << BITS) - 1u) << sh);
 }
 
 template <int BITS>
 __device__ __forceinline__ void decode_prime_quad(QuadLane &L, DecodeCarry &C, const uint32_t *w, const char *lds)
 {
-  auto record = [&](int j) { return *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + chunk_code_addr<BITS>(w, w, j)); };
+  auto record = [&](int j) { return code_record(lds, chunk_code_addr<BITS>(w, w, j)); };
   auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsWideOff + wide_addr(idxb)); };
   C.step0 = step_at(L.idxb);
   C.t0 = record(0);
   C.t1 = record(1);
   C.t2 = record(2);
-  L.idxb = clamp_idx(L.idxb + (int32_t)C.t0.z); /* from here on L.idxb runs one sample ahead */
+  L.idxb = clamp_idx(L.idxb + record_delta(C.t0)); /* from here on L.idxb runs one sample ahead */
   C.step1 = step_at(L.idxb);
   C.p = predict(L);
   C.idx_next = L.idxb;
@@ -122,14 +125,14 @@ template <int BITS, typename Finish>
 __device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, DecodeCarry &C, const uint32_t *w, const uint32_t *wn,
                                                     const char *lds, int32_t *y, Finish finish)
 {
-  auto record = [&](int j) { return *reinterpret_cast<const u32x3 *>(lds + kLdsCodeOff + chunk_code_addr<BITS>(w, wn, j)); };
+  auto record = [&](int j) { return code_record(lds, chunk_code_addr<BITS>(w, wn, j)); };
   auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsWideOff + wide_addr(idxb)); };
   uint32_t step0 = C.step0, step1 = C.step1;
-  u32x3 t0 = C.t0, t1 = C.t1, t2 = C.t2;
+  u32x2 t0 = C.t0, t1 = C.t1, t2 = C.t2;
   int32_t p = C.p;
   static_for<0, kChunk>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    const int32_t qd = mad_i24((int32_t)step0, (int32_t)t0.x, (int32_t)t0.y) >> (BITS - 1);
+    const int32_t qd = record_dequantise<BITS>(step0, t0);
     const int32_t yy = clip16(qd + p);
     lms_and_shift<kShiftSelect>(L, qd, yy);
     y[j] = finish(yy);
@@ -139,8 +142,8 @@ __device__ __forceinline__ void decode_chunk16_quad(QuadLane &L, DecodeCarry &C,
      * BEFORE the step lookup below: LDS results return in order, so the wait for a step size at
      * the top of a sample also covers the record whose delta is needed in the middle of the one
      * before - one s_waitcnt per sample, not two. */
-    int32_t idx2 = clamp_idx(L.idxb + (int32_t)t1.z);
-    const u32x3 t3 = record(j + 3);
+    int32_t idx2 = clamp_idx(L.idxb + record_delta(t1));
+    const u32x2 t3 = record(j + 3);
     pin(idx2);
     s += quad_dpp<0xB1>(s);
     pin(s);
@@ -264,7 +267,8 @@ struct ChunkCodes {
  * stores.  Stereo: the two lanes of a pair trade half of their packed samples through DPP and
  * each writes 2 x 16 contiguous bytes of L/R frames.  A vector-memory instruction costs a lone
  * wave ~17 cycles to issue whatever its width, so few wide stores beat one short per sample. */
-template <int CHF, bool QUAD>
+/* LEAD: only the first twelve samples are written (the dense decoder's alignment chunk) */
+template <int CHF, bool QUAD, bool LEAD = false>
 __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *y, uint32_t c, uint32_t ch)
 {
   if (CHF == 1) {
@@ -275,7 +279,14 @@ __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *
       v.y = perm((uint32_t)y[8 * h + 3], (uint32_t)y[8 * h + 2], 0x05040100);
       v.z = perm((uint32_t)y[8 * h + 5], (uint32_t)y[8 * h + 4], 0x05040100);
       v.w = perm((uint32_t)y[8 * h + 7], (uint32_t)y[8 * h + 6], 0x05040100);
-      reinterpret_cast<U32x4 *>(frame0 + 8 * h)->v = v;
+      if (LEAD && h == 1) {
+        u32x2 half;
+        half.x = v.x;
+        half.y = v.y;
+        reinterpret_cast<U32x2 *>(frame0 + 8 * h)->v = half;
+      } else {
+        reinterpret_cast<U32x4 *>(frame0 + 8 * h)->v = v;
+      }
     }
   } else if (CHF == 2) {
     /* per 8 samples: lane 0 writes frames 0-3 (own samples 0-3 + partner's), lane 1 frames 4-7 */
@@ -293,7 +304,8 @@ __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *
       v.y = perm(ka, ra, sel_hi);
       v.z = perm(kb, rb, sel_lo);
       v.w = perm(kb, rb, sel_hi);
-      reinterpret_cast<U32x4 *>(frame0 + 16 * h + 8 * c)->v = v;
+      /* LEAD, second half: frames 8-11 are lane 0's four; lane 1's would be samples 12-15 */
+      if (!(LEAD && h == 1) || c == 0) reinterpret_cast<U32x4 *>(frame0 + 16 * h + 8 * c)->v = v;
     }
   } else {
 #pragma unroll
@@ -400,19 +412,45 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
     using CC = ChunkCodes<BITS, (CHF ? CHF : 1)>;
     constexpr uint32_t kStride = Pack<BITS>::kChunkBytes * (CHF ? CHF : 1);
     const uint32_t body = (uint32_t)kBlockHeaderBytesPerCh * ch;
-    uint32_t full = coded / kChunk;
-    if (avail < body + CC::kLoadBytes) {
+    /* Dense mapping, 4- and 2-bit: a first chunk of TWELVE samples.  Four verbatim frames open every
+     * block, so sixteen-sample chunks put every PCM store 16 bytes (stereo) off a 64-byte boundary:
+     * at saturation the half-written 64-byte granules fell out of the L2 before the next chunk
+     * completed them and HBM saw 1.8x the output bytes (profiles/r01_saturated_pmc_summary.txt).
+     * With frames 4-15 done first, every later chunk starts at frame 16 (k + 1) - a whole granule.
+     * (Twelve 3-bit samples are one and a half pack units: 3-bit streams keep chunks of sixteen.) */
+    constexpr bool kLeadChunk = !QUAD && BITS != 3;
+    constexpr uint32_t kLead = 12, kLeadBytes = kLead * BITS / 8 * (CHF ? CHF : 1);
+    const bool lead = kLeadChunk && coded >= kLead && avail >= body + CC::kLoadBytes;
+    const uint32_t lead_bytes = lead ? kLeadBytes : 0u;
+    uint32_t full = (coded - (lead ? kLead : 0u)) / kChunk;
+    if (avail < body + lead_bytes + CC::kLoadBytes) {
       full = 0;
     } else {
-      const uint32_t fit = (avail - body - CC::kLoadBytes) / kStride + 1;
+      const uint32_t fit = (avail - body - lead_bytes - CC::kLoadBytes) / kStride + 1;
       full = full < fit ? full : fit;
     }
     const uint8_t *cp = src + body;
     int16_t *op = a.pcm + sd.pcm_offset + (first + kTaps) * ch; /* frame of this chunk's first sample, channel 0 */
     CC next;
     next.r[0] = next.r[1] = next.r[2] = next.r[3] = 0;
-    if (full) next.load(cp);
+    if (full || lead) next.load(cp);
     next.touch();
+    if constexpr (kLeadChunk) {
+      if (lead) {
+        uint32_t w[2] = {0, 0};
+        next.unpack(c, w);
+        cp += kLeadBytes;
+        if (full) next.load(cp);
+        int32_t y[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) y[j] = 0;
+        decode_chunk16<BITS, (int)kLead>(L, w, lds, y, finish);
+        next.touch();
+        if (writer) store_chunk_pcm<CHF, QUAD, true>(op, y, c, ch);
+        op += (uint64_t)kLead * ch;
+        done = kLead;
+      }
+    }
     if constexpr (QUAD) {
       /* pipeline carried across chunks: the code words of chunk k+1 are unpacked one chunk early */
       uint32_t w[2] = {0, 0}, wn[2] = {0, 0};
@@ -455,7 +493,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         op += (uint64_t)kChunk * ch;
       }
     }
-    done = full * kChunk;
+    done += full * kChunk;
   }
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 

@@ -76,7 +76,11 @@ constexpr int kChunk = 16; /* samples per unrolled chunk: a multiple of every pa
  *   step[256]   uint32   step size
  *   hr[256]     float    fl32(0.5 / step)
  *   hs[256]     float    2^(BITS-1) * hr
- *   code[16]    {int32 sm21, int32 bias, int32 delta, -}   decoder: everything a code implies
+ *   code[16]    {int32 sm21, int16 delta | bias << 16}   decoder: everything a code implies, 8 bytes -
+ *               sixteen records fill exactly one row of the 32 LDS banks, so a ds_read_b64 in which
+ *               every lane asks for a different code is conflict-free (the 16-byte {sm21, bias,
+ *               delta, -} records of round 1 put codes c and c + 8 - same magnitude, other sign - on
+ *               the same banks: 3.8 conflict cycles per lookup in the dense decoder)
  *   delta[8]    int16    encoder: index delta by magnitude
  * (A first layout used one 16-byte record per step: only 8 bank groups, SQ_LDS_BANK_CONFLICT was
  * half of all LDS cycles and lookups on the recurrence's critical path took ~100 cycles.)
@@ -86,7 +90,8 @@ constexpr int kIdxBias = 8;
 constexpr int kIdxMin = kIdxBias, kIdxMax = AAD_STEP_INDEX_MAX + kIdxBias;
 constexpr int kLdsStepOff = 0, kLdsHrOff = 1024, kLdsHsOff = 2048;
 constexpr int kLdsCodeOff = 3072;
-constexpr int kLdsDeltaOff = kLdsCodeOff + 16 * 16;
+constexpr int kLdsCodeShift = 3; /* log2 of the record size */
+constexpr int kLdsDeltaOff = kLdsCodeOff + (16 << kLdsCodeShift);
 constexpr int kLdsBytes = kLdsDeltaOff + 16;
 /* Quad kernels only: the same three values as 16-byte records {step, hr, hs, -}, addressed by
  * idxb & 0xFF0 - one instruction less than slot_addr and one lookup instead of two.  A wave of
@@ -207,15 +212,13 @@ __device__ __forceinline__ void stage_tables(char *lds)
   }
   const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
   if (threadIdx.x < (1 << BITS)) {
-    /* code -> {signed 2*mag+1, rounding bias, index delta}:
+    /* code -> {signed 2*mag+1, index delta | rounding bias << 16}:
      * qd = (step * sm21 + bias) >> (BITS-1) equals the reference's sign ? -q : q, q = (step * m21) >> (BITS-1) */
     const int code = threadIdx.x, mag = code & ((1 << kShift) - 1), neg = code >> kShift;
-    u32x4 e;
+    u32x2 e;
     e.x = (uint32_t)(neg ? -(2 * mag + 1) : (2 * mag + 1));
-    e.y = neg ? (1u << kShift) - 1u : 0u;
-    e.z = (uint32_t)(int32_t)dt[mag];
-    e.w = 0;
-    *reinterpret_cast<u32x4 *>(lds + kLdsCodeOff + (code << 4)) = e;
+    e.y = ((uint32_t)(int32_t)dt[mag] & 0xFFFFu) | ((neg ? (1u << kShift) - 1u : 0u) << 16);
+    *reinterpret_cast<u32x2 *>(lds + kLdsCodeOff + (code << kLdsCodeShift)) = e;
   }
   if (threadIdx.x < 8) reinterpret_cast<int16_t *>(lds + kLdsDeltaOff)[threadIdx.x] = dt[threadIdx.x & ((1 << kShift) - 1)];
   __syncthreads();
@@ -240,6 +243,20 @@ __device__ __forceinline__ int32_t sx24(int32_t v) { return (int32_t)((uint32_t)
 __device__ __forceinline__ int32_t mad_i24(int32_t a, int32_t b, int32_t c)
 {
   return (int32_t)((uint32_t)(sx24(a) * sx24(b)) + (uint32_t)c);
+}
+
+/* the decoder's per-code record (stage_tables): the delta is read as the low half by the index add
+ * itself (v_add_u32_sdwa), the bias costs one shift.  (Tried: a v_dot2_i32_i16 against {step, 0} or a
+ * v_mad_i32_i16 reading packed halves in place - the first is followed by three wait states on
+ * gfx950, the second, as inline asm, by one; the compiler's own 16-bit multiply-add sign-extends both
+ * factors first.) */
+__device__ __forceinline__ u32x2 code_record(const char *lds, uint32_t code_times_8) { return *reinterpret_cast<const u32x2 *>(lds + kLdsCodeOff + code_times_8); }
+__device__ __forceinline__ int32_t record_delta(const u32x2 &t) { return (int32_t)(int16_t)t.y; }
+/* (step * sm21 + bias) >> (BITS - 1): the dequantised difference, sign included */
+template <int BITS>
+__device__ __forceinline__ int32_t record_dequantise(uint32_t step, const u32x2 &t)
+{
+  return mad_i24((int32_t)step, (int32_t)t.x, (int32_t)(t.y >> 16)) >> (BITS - 1);
 }
 
 /* (16384 + sum h*w) >> 15 with int32 wraparound - reference src/aad_encoder.c:359-363.
