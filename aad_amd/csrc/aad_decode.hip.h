@@ -267,8 +267,18 @@ struct ChunkCodes {
  * stores.  Stereo: the two lanes of a pair trade half of their packed samples through DPP and
  * each writes 2 x 16 contiguous bytes of L/R frames.  A vector-memory instruction costs a lone
  * wave ~17 cycles to issue whatever its width, so few wide stores beat one short per sample. */
-/* LEAD: only the first twelve samples are written (the dense decoder's alignment chunk) */
-template <int CHF, bool QUAD, bool LEAD = false>
+/* a 16-byte store at any (2-byte) alignment; NT = non-temporal (streamed out: the dense decoder's PCM
+ * is written once and never read back, and at saturation the L2 is better spent on the code bytes
+ * every block comes back to eight times per 128-byte line) */
+typedef uint32_t u32x4_u2 __attribute__((ext_vector_type(4), aligned(2)));
+template <bool NT>
+__device__ __forceinline__ void store_u32x4(int16_t *p, u32x4 v)
+{
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_u2 *>(p));
+  else reinterpret_cast<U32x4 *>(p)->v = v;
+}
+
+template <int CHF, bool QUAD, bool NT = false>
 __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *y, uint32_t c, uint32_t ch)
 {
   if (CHF == 1) {
@@ -279,14 +289,7 @@ __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *
       v.y = perm((uint32_t)y[8 * h + 3], (uint32_t)y[8 * h + 2], 0x05040100);
       v.z = perm((uint32_t)y[8 * h + 5], (uint32_t)y[8 * h + 4], 0x05040100);
       v.w = perm((uint32_t)y[8 * h + 7], (uint32_t)y[8 * h + 6], 0x05040100);
-      if (LEAD && h == 1) {
-        u32x2 half;
-        half.x = v.x;
-        half.y = v.y;
-        reinterpret_cast<U32x2 *>(frame0 + 8 * h)->v = half;
-      } else {
-        reinterpret_cast<U32x4 *>(frame0 + 8 * h)->v = v;
-      }
+      store_u32x4<NT>(frame0 + 8 * h, v);
     }
   } else if (CHF == 2) {
     /* per 8 samples: lane 0 writes frames 0-3 (own samples 0-3 + partner's), lane 1 frames 4-7 */
@@ -304,8 +307,7 @@ __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *
       v.y = perm(ka, ra, sel_hi);
       v.z = perm(kb, rb, sel_lo);
       v.w = perm(kb, rb, sel_hi);
-      /* LEAD, second half: frames 8-11 are lane 0's four; lane 1's would be samples 12-15 */
-      if (!(LEAD && h == 1) || c == 0) reinterpret_cast<U32x4 *>(frame0 + 16 * h + 8 * c)->v = v;
+      store_u32x4<NT>(frame0 + 16 * h + 8 * c, v);
     }
   } else {
 #pragma unroll
@@ -388,39 +390,40 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
     return y;
   };
 
+  constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
+  const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
+  uint32_t done = 0; /* coded samples finished */
+
+  /* Dense mapping, 4- and 2-bit: the block opens with ONE chunk of the four verbatim frames plus
+   * TWELVE decoded samples.  Chunks of sixteen decoded samples behind four verbatim frames put every
+   * PCM store 16 bytes (stereo) off a 64-byte boundary: at saturation the half-written 64-byte
+   * granules fell out of the L2 before the next chunk completed them and HBM saw 1.8x the output
+   * bytes (profiles/r01_saturated_pmc_summary.txt).  This way every store of a block whose first
+   * frame is 64-byte aligned is a whole granule.  (Twelve 3-bit samples are one and a half pack
+   * units: 3-bit streams keep chunks of sixteen.) */
+  constexpr bool kLeadChunk = CHF != 0 && !QUAD && BITS != 3;
+  constexpr uint32_t kLead = 12, kLeadBytes = kLead * BITS / 8 * (CHF ? CHF : 1);
+  constexpr uint32_t kLeadLoadBytes = ChunkCodes<BITS, (CHF ? CHF : 1)>::kLoadBytes;
+  const bool lead = kLeadChunk && coded >= kLead && avail >= (uint32_t)kBlockHeaderBytesPerCh * ch + kLeadLoadBytes;
+
   /* the first four samples are stored verbatim in the header - reference :386-391 */
-  {
-    const int32_t y0 = finish(H.h3), y1 = finish(H.h2), y2 = finish(H.h1), y3 = finish(H.h0);
-    if (writer) {
-      if (n > 0) dst[0] = (int16_t)y0;
-      if (n > 1) dst[ch] = (int16_t)y1;
-      if (n > 2) dst[2 * ch] = (int16_t)y2;
-      if (n > 3) dst[3 * ch] = (int16_t)y3;
-    }
+  const int32_t y0 = finish(H.h3), y1 = finish(H.h2), y2 = finish(H.h1), y3 = finish(H.h0);
+  if (writer && !lead) {
+    if (n > 0) dst[0] = (int16_t)y0;
+    if (n > 1) dst[ch] = (int16_t)y1;
+    if (n > 2) dst[2 * ch] = (int16_t)y2;
+    if (n > 3) dst[3 * ch] = (int16_t)y3;
   }
   using S = std::conditional_t<QUAD, QuadLane, Lane>;
   S L;
   if constexpr (QUAD) L = to_quad<false>(H, tap); else L = H;
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
-  constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
-  const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
-  uint32_t done = 0; /* coded samples finished */
-
   if (CHF != 0) {
     /* full 16-sample chunks whose wide load stays inside the stream's bytes */
     using CC = ChunkCodes<BITS, (CHF ? CHF : 1)>;
     constexpr uint32_t kStride = Pack<BITS>::kChunkBytes * (CHF ? CHF : 1);
     const uint32_t body = (uint32_t)kBlockHeaderBytesPerCh * ch;
-    /* Dense mapping, 4- and 2-bit: a first chunk of TWELVE samples.  Four verbatim frames open every
-     * block, so sixteen-sample chunks put every PCM store 16 bytes (stereo) off a 64-byte boundary:
-     * at saturation the half-written 64-byte granules fell out of the L2 before the next chunk
-     * completed them and HBM saw 1.8x the output bytes (profiles/r01_saturated_pmc_summary.txt).
-     * With frames 4-15 done first, every later chunk starts at frame 16 (k + 1) - a whole granule.
-     * (Twelve 3-bit samples are one and a half pack units: 3-bit streams keep chunks of sixteen.) */
-    constexpr bool kLeadChunk = !QUAD && BITS != 3;
-    constexpr uint32_t kLead = 12, kLeadBytes = kLead * BITS / 8 * (CHF ? CHF : 1);
-    const bool lead = kLeadChunk && coded >= kLead && avail >= body + CC::kLoadBytes;
     const uint32_t lead_bytes = lead ? kLeadBytes : 0u;
     uint32_t full = (coded - (lead ? kLead : 0u)) / kChunk;
     if (avail < body + lead_bytes + CC::kLoadBytes) {
@@ -442,11 +445,13 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         cp += kLeadBytes;
         if (full) next.load(cp);
         int32_t y[kChunk];
-#pragma unroll
-        for (int j = 0; j < kChunk; j++) y[j] = 0;
-        decode_chunk16<BITS, (int)kLead>(L, w, lds, y, finish);
+        y[0] = y0;
+        y[1] = y1;
+        y[2] = y2;
+        y[3] = y3;
+        decode_chunk16<BITS, (int)kLead>(L, w, lds, y + kTaps, finish);
         next.touch();
-        if (writer) store_chunk_pcm<CHF, QUAD, true>(op, y, c, ch);
+        if (writer) store_chunk_pcm<CHF, QUAD, true>(op - (uint64_t)kTaps * ch, y, c, ch); /* frames 0-15 of the block */
         op += (uint64_t)kLead * ch;
         done = kLead;
       }
@@ -489,7 +494,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         int32_t y[kChunk];
         decode_chunk16<BITS>(L, w, lds, y, finish);
         next.touch();
-        if (writer) store_chunk_pcm<CHF, QUAD>(op, y, c, ch);
+        if (writer) store_chunk_pcm<CHF, QUAD, true>(op, y, c, ch);
         op += (uint64_t)kChunk * ch;
       }
     }
