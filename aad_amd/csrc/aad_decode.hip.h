@@ -184,6 +184,8 @@ struct DecodeArgs {
   uint32_t header_bytes; /* 31 (file image) or 0 (bare block) */
   uint32_t mid_side;
   uint32_t bits;
+  uint32_t stream_stores; /* dense stereo kernel: every chunk store of every block is a whole 64-byte granule (host-checked): launch the NT instantiation */
+  uint32_t reserved;
   UniformLayout uni;
 };
 
@@ -267,7 +269,7 @@ struct ChunkCodes {
  * stores.  Stereo: the two lanes of a pair trade half of their packed samples through DPP and
  * each writes 2 x 16 contiguous bytes of L/R frames.  A vector-memory instruction costs a lone
  * wave ~17 cycles to issue whatever its width, so few wide stores beat one short per sample. */
-/* a 16-byte store at any (2-byte) alignment; NT = non-temporal (streamed out: the dense decoder's PCM
+/* a 16-byte store at any (2-byte) alignment; nt = non-temporal (streamed out: the dense decoder's PCM
  * is written once and never read back, and at saturation the L2 is better spent on the code bytes
  * every block comes back to eight times per 128-byte line) */
 typedef uint32_t u32x4_u2 __attribute__((ext_vector_type(4), aligned(2)));
@@ -278,6 +280,8 @@ __device__ __forceinline__ void store_u32x4(int16_t *p, u32x4 v)
   else reinterpret_cast<U32x4 *>(p)->v = v;
 }
 
+/* NT: a compile-time choice (a run-time flag in the chunk loop cost the dense kernel its software
+ * pipelining: 0.66 -> 1.04 ms at saturation); see DecodeArgs::stream_stores */
 template <int CHF, bool QUAD, bool NT = false>
 __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *y, uint32_t c, uint32_t ch)
 {
@@ -319,10 +323,14 @@ __device__ __forceinline__ void store_chunk_pcm(int16_t *frame0, const int32_t *
  * Block-parallel decode (reference src/aad_decoder.c:321-475, looped by :514-534).
  * CHF: 1 / 2 = specialised channel counts with wide chunk loads, 0 = any channel count (byte loads).
  */
-template <int BITS, int CHF, bool MS, bool QUAD>
+/* NT: the dense stereo kernel's PCM stores are non-temporal - launched only where every store is a
+ * whole 64-byte granule (DecodeArgs::stream_stores): a partial granule written around the L2 is a
+ * read-modify-write at the memory (mono and unaligned geometries ran up to 2.6x slower with it) */
+template <int BITS, int CHF, bool MS, bool QUAD, bool NT = false>
 __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
+  static_assert(!NT || (CHF == 2 && !QUAD && BITS != 3), "streamed stores: dense stereo kernel with the 16-frame lead chunk");
   __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, QUAD>(lds);
@@ -451,7 +459,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         y[3] = y3;
         decode_chunk16<BITS, (int)kLead>(L, w, lds, y + kTaps, finish);
         next.touch();
-        if (writer) store_chunk_pcm<CHF, QUAD, true>(op - (uint64_t)kTaps * ch, y, c, ch); /* frames 0-15 of the block */
+        if (writer) store_chunk_pcm<CHF, QUAD, NT>(op - (uint64_t)kTaps * ch, y, c, ch); /* frames 0-15 of the block */
         op += (uint64_t)kLead * ch;
         done = kLead;
       }
@@ -494,7 +502,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         int32_t y[kChunk];
         decode_chunk16<BITS>(L, w, lds, y, finish);
         next.touch();
-        if (writer) store_chunk_pcm<CHF, QUAD, true>(op, y, c, ch);
+        if (writer) store_chunk_pcm<CHF, QUAD, NT>(op, y, c, ch);
         op += (uint64_t)kChunk * ch;
       }
     }

@@ -163,17 +163,34 @@ bool upload(AADHipContext *ctx, T **dst, const T *src, size_t count)
  * workgroups so four waves share one LDS copy of the tables. */
 unsigned pick_workgroup(uint64_t threads) { return threads <= 64ull * 1024ull ? 64u : 256u; }
 
-/* Lane mapping: "quad" (four lanes per recurrence, fewer instructions per sample) while the
- * batch cannot fill the chip anyway, "dense" (one lane per recurrence, fewest total
- * instructions) beyond that.  The crossover is two quad-waves per SIMD.  A context option
- * (AADHip_ContextSetOption, default from AAD_HIP_MAPPING at context creation) forces one; the
- * parity tests run all of them. */
-bool pick_quad(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels)
+/* Lane mapping by batch size.  "quad" (four lanes per recurrence, fewer instructions on the
+ * recurrence's critical path) while the batch cannot fill the chip anyway, "dense" (one lane per
+ * recurrence, fewest total instructions) beyond; the decoder has the split quad kernel below the
+ * fused one.  The crossovers were measured per (bits, channels) geometry on one-block streams
+ * (tools/mapping_crossover.py, profiles/r02_mapping_crossover.jsonl): they sit where the quad
+ * mappings start to put a second wave on a SIMD (4 x 16384 lanes = one wave on each of the 1024
+ * SIMDs) and depend on the geometry only for the split decoder, whose 3-bit stereo unpacking is the
+ * most expensive strand-1 work.  A context option (AADHip_ContextSetOption, default from
+ * AAD_HIP_MAPPING at context creation) forces one mapping; the parity tests run all of them. */
+struct MappingLimits {
+  uint32_t encode_quad;  /* recurrences up to which encode uses the quad mapping */
+  uint32_t decode_split; /* ... decode uses the split quad decoder */
+  uint32_t decode_fused; /* ... the fused quad decoder; dense beyond */
+};
+
+MappingLimits mapping_limits(uint32_t bits, uint32_t channels)
+{
+  MappingLimits m = {16384u, 12288u, 16384u};
+  if (bits == 3 && channels == 2) m.decode_split = 8192u;
+  return m;
+}
+
+bool pick_quad(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels, uint32_t bits)
 {
   if (channels > 2) return false;
   if (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_DENSE) return false;
   if (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_QUAD || ctx->lane_mapping == AAD_HIP_LANE_MAPPING_QUAD_FUSED) return true;
-  return recurrences * 4 <= 2ull * 1024ull * 64ull;
+  return recurrences <= mapping_limits(bits, channels).encode_quad;
 }
 
 template <int BITS, bool QUAD, bool TRIALS, bool DUAL>
@@ -203,7 +220,7 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
 {
   const hipStream_t stream = ctx->stream;
   const uint64_t lanes = (uint64_t)a.num_streams * a.channels;
-  const bool quad = pick_quad(ctx, lanes, a.channels);
+  const bool quad = pick_quad(ctx, lanes, a.channels, BITS);
   const bool dual = pick_dual(ctx, a, quad);
   const uint64_t threads = quad ? lanes * (dual ? 8 : 4) : lanes;
   const unsigned wg = pick_workgroup(threads);
@@ -223,10 +240,23 @@ void launch_decode_mapped(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipSt
 {
   if (a.channels == 1)
     hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 1, false, QUAD>), grid, block, 0, stream, a);
-  else if (a.channels == 2 && a.mid_side)
+  else if (a.channels == 2 && a.mid_side) {
+    if constexpr (!QUAD && BITS != 3) {
+      if (a.stream_stores) {
+        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, false, true>), grid, block, 0, stream, a);
+        return;
+      }
+    }
     hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, QUAD>), grid, block, 0, stream, a);
-  else if (a.channels == 2)
+  } else if (a.channels == 2) {
+    if constexpr (!QUAD && BITS != 3) {
+      if (a.stream_stores) {
+        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, false, true>), grid, block, 0, stream, a);
+        return;
+      }
+    }
     hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, QUAD>), grid, block, 0, stream, a);
+  }
   else if constexpr (!QUAD)
     hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false, false>), grid, block, 0, stream, a);
 }
@@ -236,12 +266,10 @@ void launch_decode_mapped(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipSt
  * unreasonably large. */
 constexpr uint64_t kMaxResidualBytes = 1ull << 30;
 
-/* Decode mapping by batch size (tools/decode_crossover.py, one-block stereo streams on MI355X):
- * the split quad decoder wins up to ~8 k recurrences (one or two 16-wave workgroups per CU), the
- * fused quad kernel from there to ~20 k, the dense mapping beyond.  AAD_HIP_MAPPING forces one. */
+/* Decode mapping by batch size: see mapping_limits.  The context option forces one. */
 enum class DecodeMapping { Dense, QuadFused, QuadSplit };
 
-DecodeMapping pick_decode_mapping(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels)
+DecodeMapping pick_decode_mapping(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels, uint32_t bits)
 {
   if (channels > 2) return DecodeMapping::Dense;
   switch (ctx->lane_mapping) {
@@ -250,15 +278,16 @@ DecodeMapping pick_decode_mapping(const AADHipContext *ctx, uint64_t recurrences
     case AAD_HIP_LANE_MAPPING_QUAD: return DecodeMapping::QuadSplit;
     default: break;
   }
-  if (recurrences <= 8192) return DecodeMapping::QuadSplit;
-  if (recurrences <= 20480) return DecodeMapping::QuadFused;
+  const MappingLimits m = mapping_limits(bits, channels);
+  if (recurrences <= m.decode_split) return DecodeMapping::QuadSplit;
+  if (recurrences <= m.decode_fused) return DecodeMapping::QuadFused;
   return DecodeMapping::Dense;
 }
 
 bool want_split_decode(const AADHipContext *ctx, const aad::DecodeArgs &a, uint64_t *bytes, uint32_t *stride)
 {
   const uint64_t recurrences = a.total_blocks * a.channels;
-  if (pick_decode_mapping(ctx, recurrences, a.channels) != DecodeMapping::QuadSplit) return false;
+  if (pick_decode_mapping(ctx, recurrences, a.channels, a.bits) != DecodeMapping::QuadSplit) return false;
   /* 64-bit: samples_per_block comes straight from a file header and may be anything */
   const uint64_t coded = a.samples_per_block > 4 ? (uint64_t)a.samples_per_block - 4 : 0;
   const uint64_t row = (coded + 15u) / 16u * 16u + 16u;
@@ -274,7 +303,7 @@ void launch_decode(const AADHipContext *ctx, const aad::DecodeArgs &a, int32_t *
   const hipStream_t stream = ctx->stream;
   if (residual != nullptr && aad::launch_decode_split(a, residual, residual_stride, stream)) return;
   const uint64_t lanes = a.total_blocks * a.channels;
-  const bool quad = pick_decode_mapping(ctx, lanes, a.channels) != DecodeMapping::Dense;
+  const bool quad = pick_decode_mapping(ctx, lanes, a.channels, BITS) != DecodeMapping::Dense;
   const uint64_t threads = quad ? lanes * 4 : lanes;
   const unsigned wg = pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
@@ -359,6 +388,13 @@ AADApiResult decode_plan_init(const struct AADHeaderInfo *format, int32_t has_fi
   }
   args->mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
   args->bits = h.bits_per_sample;
+  /* Dense stereo 4-/2-bit decode opens every block with a 16-frame chunk, so its stores are whole
+   * 64-byte granules exactly when every block's first frame is 64-byte aligned: a uniform layout
+   * whose stream pitch and block length (in PCM bytes) are multiples of 64.  Only then are they
+   * issued non-temporal (the base pointer is checked at run time). */
+  args->stream_stores = args->uni.enabled && h.num_channels == 2 && h.bits_per_sample != 3 &&
+                        (args->uni.pcm_base * 2) % 64 == 0 && (args->uni.pcm_stride * 2) % 64 == 0 &&
+                        ((uint64_t)h.num_samples_per_block * 4) % 64 == 0;
   return AAD_APIRESULT_OK;
 }
 
@@ -644,6 +680,7 @@ AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *
   aad::DecodeArgs a = plan->args;
   a.data = device_data;
   a.pcm = device_pcm;
+  if ((reinterpret_cast<uintptr_t>(device_pcm) & 63u) != 0) a.stream_stores = 0;
   return run_decode(ctx, a);
 }
 
@@ -880,6 +917,7 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
     a.block_prefix = reinterpret_cast<const uint64_t *>(din + table_bytes);
     a.data = din + data_off;
     a.pcm = static_cast<int16_t *>(ctx->out[b].dev);
+    if ((reinterpret_cast<uintptr_t>(a.pcm) & 63u) != 0) a.stream_stores = 0;
     if (run_decode(ctx, a) != AAD_APIRESULT_OK) break;
     if (out_bytes && !hip_ok(ctx, hipMemcpyAsync(ctx->out[b].host, ctx->out[b].dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H block")) break;
     if (!hip_ok(ctx, hipEventRecord(ctx->chunk_done[b], ctx->stream), "hipEventRecord")) break;

@@ -419,15 +419,18 @@ def test_extreme_block_sizes(engine, mapping):
             assert np.array_equal(dec[s], ob.decode(images[s])[0]), (ch, bits, mbs)
 
 
-@pytest.mark.parametrize("streams,bits,ch", [(3000, 4, 2), (7000, 4, 1), (9000, 3, 2), (12000, 2, 2)])
+@pytest.mark.parametrize("streams,bits,ch", [(3000, 4, 2), (7000, 4, 1), (6144, 4, 2), (6145, 4, 2), (8192, 4, 2), (8193, 4, 2),
+                                             (4096, 3, 2), (5000, 3, 2), (9000, 3, 2), (12000, 2, 2), (16384, 2, 1), (17000, 3, 1)])
 def test_decode_mapping_ranges_auto(engine, streams, bits, ch):
-    """The host's own choice of decode mapping across its thresholds (mapping option "auto"): split
-    decoder with the residuals in a device scratch buffer (more than one workgroup per CU),
-    fused quad kernel, dense kernel - one-block streams, sampled against the oracle, and the whole
-    batch through the round trip decode(encode(x)) == oracle decode."""
+    """The host's own choice of mapping on both sides of every threshold of its per-geometry table
+    (mapping option "auto"; aad_hip_engine.hip mapping_limits: encode quad up to 16384 recurrences,
+    decode split up to 12288 - 8192 for 3-bit stereo -, fused up to 16384, dense beyond): split
+    decoder with the residuals in LDS / in a device scratch buffer, fused quad kernel, dense kernel -
+    one-block streams, sampled against the oracle, and the whole batch through the round trip
+    decode(encode(x)) == oracle decode."""
     import torch
     engine.set_mapping("auto")
-    spb = {4: 1984, 3: 2632, 2: 3960}[bits] // ch
+    spb = ob.geometry(1024, ch, bits)[2]
     base = synth_pcm(500, spb, ch, seed=2024 + streams)
     pcm = np.concatenate([base] * (-(-streams // 500)))[:streams]
     d_pcm = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
