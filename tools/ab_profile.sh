@@ -24,3 +24,4 @@ for v in "$@"; do
   export AAD_HIP_LIBRARY=$R/$v
   one variant$i
 done
+find $O -name "*.db" -delete

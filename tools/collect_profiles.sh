@@ -22,3 +22,5 @@ python3 tools/hbm_traffic.py $O/fetch $O/write 1000 992 $O/hbm_traffic.json
 cp $O/hbm_traffic.json profiles/r02_hbm_traffic.json   # so that the bench line below quotes THIS measurement
 python3 bench.py > $O/bench_line.json 2> $O/bench_err.log
 tail -c 600 $O/bench_line.json
+# the raw rocpd databases are tens of MB per pass: only the summaries travel back
+find $O -name "*.db" -delete

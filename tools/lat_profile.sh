@@ -11,3 +11,4 @@ rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_IFETCH SQ_IFETCH_LEVEL SQ_IN
 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INSTS_BRANCH -d $O/c -- $CMD > $O/c.log 2>&1
 python3 tools/pmc_db_summary.py $O 2
 tail -3 $O/a.log
+find $O -name "*.db" -delete
