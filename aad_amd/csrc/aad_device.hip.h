@@ -100,6 +100,17 @@ constexpr int kLdsBytes = kLdsDeltaOff + 16;
 constexpr int kLdsWideOff = (kLdsBytes + 15) & ~15;
 constexpr int kLdsBytesQuad = kLdsWideOff + AAD_STEP_TABLE_LEN * 16;
 __device__ __forceinline__ uint32_t wide_addr(int32_t idxb) { return (uint32_t)idxb & 0xFF0u; }
+/* Quad ENCODER (tap-major lanes): four copies of the wide records, interleaved - slot i, copy r at
+ * 64 i + 16 r.  A ds_read_b96 is served eight lanes per cycle; in the tap-major layout those are
+ * two taps of FOUR different recurrences (r = lane & 3), i.e. four different records, and 16-byte
+ * records collide whenever two slots agree mod 8 (measured: 7.8 conflict cycles per lookup, on the
+ * recurrence's critical path).  With copy r confined to banks 4r .. 4r+2 of each 16-bank half the
+ * four reads of a cycle never meet.  The encoder keeps its step index scaled by four for this
+ * (J = 4 * idxb; the slot is then J >> 6 and the address (J & 0x3FC0) | 16 r: one v_and_or_b32,
+ * where the unscaled form took one v_and_b32), the deltas come scaled as well. */
+constexpr int kLdsBytesQuadEnc = kLdsWideOff + AAD_STEP_TABLE_LEN * 64;
+constexpr int kIdxScale = 4;
+__device__ __forceinline__ uint32_t wide4_addr(int32_t j, uint32_t copy_off) { return ((uint32_t)j & 0x3FC0u) | copy_off; }
 
 /* byte offset of the step index's slot in the dword arrays */
 __device__ __forceinline__ uint32_t slot_addr(int32_t idxb) { return ((uint32_t)idxb >> 2) & 0x3FCu; }
@@ -191,7 +202,7 @@ struct Pack {
 };
 
 /* stage the tables into LDS; every thread of the workgroup must call this */
-template <int BITS, bool QUAD, int WIDE_STEP_SHIFT = 0>
+template <int BITS, bool QUAD, int WIDE_STEP_SHIFT = 0, bool WIDE4 = false>
 __device__ __forceinline__ void stage_tables(char *lds)
 {
   constexpr int kShift = BITS - 1;
@@ -207,7 +218,12 @@ __device__ __forceinline__ void stage_tables(char *lds)
       e.y = __float_as_uint(hr);
       e.z = __float_as_uint(hs);
       e.w = 0;
-      *reinterpret_cast<u32x4 *>(lds + kLdsWideOff + (i << 4)) = e;
+      if (WIDE4) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) *reinterpret_cast<u32x4 *>(lds + kLdsWideOff + (i << 6) + (r << 4)) = e;
+      } else {
+        *reinterpret_cast<u32x4 *>(lds + kLdsWideOff + (i << 4)) = e;
+      }
     }
   }
   const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);

@@ -35,6 +35,20 @@ __device__ __forceinline__ int32_t index_delta_arith(uint32_t mag)
   }
 }
 
+/* the same delta times kIdxScale (4), for the quad encoder's scaled step index */
+template <int BITS>
+__device__ __forceinline__ int32_t index_delta_arith_x4(uint32_t mag)
+{
+  if (BITS == 4) {
+    const uint32_t corr = __builtin_amdgcn_perm(0u, 0x00585450u, mag) & 0xFFu; /* 4 * {20, 21, 22, 0, ...} */
+    return (int32_t)(8u << mag) - (int32_t)corr;
+  } else if (BITS == 3) {
+    return mag < 2 ? 4 * (int32_t)mag - 64 : (int32_t)(8u << (2u * mag));
+  } else {
+    return mag ? 160 : -56;
+  }
+}
+
 /* one encoder step - reference src/aad_encoder.c:343-410.  Returns the code; qd is the
  * dequantised difference (the reference's quantize_error).  Plain form, used for tails and the
  * trial search; the bulk goes through encode_chunk16.  S = Lane or QuadLane. */
@@ -158,12 +172,16 @@ struct EncodeCarry {
   u32x3 e;         /* {step, hr, hs} of the coming sample */
   int32_t p, d, m; /* its prediction, difference and sign mask */
   float f;         /* (float)d */
+  int32_t j;       /* kIdxScale * (biased step index): the chunk bodies' own form of L.idxb */
+  uint32_t copy;   /* this lane's copy of the wide records: 16 * (recurrence slot & 3) */
 };
 
 template <int BITS>
 __device__ __forceinline__ void encode_prime_quad(QuadLane &L, EncodeCarry &C, int32_t x0, const char *lds)
 {
-  C.e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
+  C.j = L.idxb * kIdxScale;
+  C.copy = (threadIdx.x & 3u) << 4;
+  C.e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide4_addr(C.j, C.copy));
   C.p = predict<kEncTM>(L);
   C.d = x0 - C.p;
   C.m = C.d >> 31;
@@ -192,7 +210,8 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     return k < kChunk ? x[k] : xn0;
   };
   u32x3 e = C.e;
-  int32_t p = C.p, d = C.d, m = C.m;
+  int32_t p = C.p, d = C.d, m = C.m, idxj = C.j;
+  const uint32_t copy = C.copy;
   float f = C.f;
   static_for<0, kChunk>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -200,8 +219,8 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)),
                              Pack<BITS>::kMagMax);
     const uint32_t step2_j = e.x; /* 2 * step (stage_tables<.., WIDE_STEP_SHIFT = 1>) */
-    L.idxb = clamp_idx(L.idxb + index_delta_arith<BITS>(mag));
-    e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide_addr(L.idxb));
+    idxj = min(max(idxj + index_delta_arith_x4<BITS>(mag), kIdxScale * kIdxMin), kIdxScale * kIdxMax);
+    e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide4_addr(idxj, copy));
     __builtin_amdgcn_sched_barrier(0);
     /* B: q = (step * (2 mag + 1)) >> (BITS-1) as ONE high multiply:
      * (2 step) * ((2 mag + 1) << (32 - BITS)) = step * (2 mag + 1) * 2^(33 - BITS), upper 32 bits.
@@ -256,6 +275,8 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
   C.d = d;
   C.m = m;
   C.f = f;
+  C.j = idxj;
+  L.idxb = idxj >> 2; /* (kIdxScale = 4) the unscaled form everything outside the chunk bodies uses; dead code unless read */
 }
 
 /* ================================================================================ encode == */
@@ -709,9 +730,9 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
-  __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
+  __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuadEnc : kLdsBytes];
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
-  stage_tables<BITS, QUAD, 1>(lds);
+  stage_tables<BITS, QUAD, 1, QUAD>(lds);
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   const uint32_t ch = CHF ? CHF : a.channels;
