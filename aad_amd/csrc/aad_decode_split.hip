@@ -9,6 +9,8 @@
  * result of the one just before it).  The same flag makes no difference to the encoder and is
  * not applied to the other kernels.
  */
+#include <cstring>
+
 #include "aad_decode_split.hip.h"
 #include "aad_decode_split_launch.h"
 
@@ -52,3 +54,21 @@ bool launch_decode_split(const DecodeArgs &args, int32_t *residual, uint32_t res
 }
 
 } /* namespace aad */
+
+#if AAD_PHASE_TIMING
+/* measurement builds only: copy out and reset the phase log of this unit's kernels
+ * (kernel entry | tables written | barrier | strand 1 done | barrier | header parsed, first frames out |
+ *  first loads + prime | chunk loop | tail) */
+extern "C" uint32_t AADHipDebug_ReadSplitPhaseTimes(uint64_t *out, uint32_t capacity)
+{
+  uint32_t n = 0, zero = 0;
+  uint64_t host[512];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(aad::g_phase_count), sizeof(n));
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(aad::g_phase_times), sizeof(host));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(aad::g_phase_count), &zero, sizeof(zero));
+  if (n > capacity) n = capacity;
+  memcpy(out, host, sizeof(uint64_t) * n);
+  return n;
+}
+#endif

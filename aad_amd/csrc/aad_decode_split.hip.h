@@ -306,6 +306,7 @@ __device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint6
     }
   }
   QuadLane L = to_quad<false>(H, tap);
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
   const uint32_t full = coded / kChunk;
   int16_t *op = a.d.pcm + blk.pcm_first + (uint64_t)kTaps * ch; /* frame of the chunk's first sample, channel 0 */
@@ -376,11 +377,13 @@ __device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint6
         if (writer) store_chunk_pcm<CHF, true>(op + (uint64_t)k * kChunk * ch, y, c, ch);
       }
     };
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
     for (uint32_t k = 0; k < full; k += 3) {
       one(k, b0, b1, b2);
       if (k + 1 < full) one(k + 1, b1, b2, b0);
       if (k + 2 < full) one(k + 2, b2, b0, b1);
     }
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
     if constexpr (COOP) {
       if (full) flush_chunk(full - 1, l_row[((full - 1) & 1u) * 128u], r_row[((full - 1) & 1u) * 128u]);
     }
@@ -405,6 +408,7 @@ __device__ __forceinline__ void predict_for_quad(const SplitDecodeArgs &a, uint6
       }
     });
   }
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 }
 
 /*
@@ -429,12 +433,15 @@ __global__ void __launch_bounds__(1024) decode_split_kernel(SplitDecodeArgs a)
   __shared__ int32_t s_delta[8];
   __shared__ __attribute__((aligned(16))) int32_t s_res[LDSRES ? 16 * kLdsResidualRow : 4];
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[2 * 16 * 8]; /* stereo output staging of the recurrence wave */
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   for (uint32_t i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) s_step[i] = c_step_table[i];
   if (threadIdx.x < 8) {
     const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
     s_delta[threadIdx.x] = dt[threadIdx.x & Pack<BITS>::kMagMax];
   }
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   __syncthreads();
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   {
     const uint32_t w = threadIdx.x >> 6;
     const uint64_t rec = (uint64_t)blockIdx.x * 16u + w;
@@ -442,8 +449,10 @@ __global__ void __launch_bounds__(1024) decode_split_kernel(SplitDecodeArgs a)
       residuals_for_recurrence<BITS>(a, rec, threadIdx.x & 63u, s_step, s_delta,
                                      LDSRES ? s_res + w * kLdsResidualRow : a.residual + rec * a.residual_stride);
   }
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   /* the residuals are in LDS / in memory before wave 0 reads them (workgroup-scope release/acquire) */
   __syncthreads();
+  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   if (threadIdx.x >= 64) return;
   const uint64_t thread = (uint64_t)blockIdx.x * 64u + threadIdx.x;
   const uint64_t rec = thread >> 2;

@@ -44,4 +44,16 @@ for rep in range(3):
     torch.cuda.synchronize()
     n = lib.AADHipDebug_ReadPhaseTimes(buf.ctypes.data, 512)
 print("decode phases, cycles between marks:", " ".join(str(int(x)) for x in np.diff(buf[:n].astype(np.int64))), flush=True)
+# split decoder (its own translation unit): entry | tables written | barrier | strand 1 | barrier |
+# header parsed + first frames | first loads + prime | chunk loop | tail
+try:
+    lib.AADHipDebug_ReadSplitPhaseTimes.argtypes = [C.c_void_p, C.c_uint32]
+    lib.AADHipDebug_ReadSplitPhaseTimes.restype = C.c_uint32
+    for rep in range(3):
+        dplan.run(img, out)
+        torch.cuda.synchronize()
+        n = lib.AADHipDebug_ReadSplitPhaseTimes(buf.ctypes.data, 512)
+    print("split decode phases, cycles between marks:", " ".join(str(int(x)) for x in np.diff(buf[:n].astype(np.int64))), flush=True)
+except AttributeError:
+    pass
 engine.close()
