@@ -197,9 +197,18 @@ __device__ __forceinline__ void encode_prime_quad(QuadLane &L, EncodeCarry &C, i
  *            loaded, the channel-1 lane having loaded from two bytes further on
  * The subtract reads the halves directly (v_sub_u32_sdwa): no per-sample extraction. */
 enum { kWide = 0, kPairs = 1, kFrames = 2 };
-template <int BITS, bool EMIT, int FORMAT = kWide>
+/* a filler that emits nothing */
+struct NoFill {
+  template <class J> __device__ __forceinline__ void operator()(J) const {}
+};
+
+/* fill(integral_constant<int, j>) is invoked once per sample j, in the first DPP gap: one independent
+ * instruction there replaces the s_nop the gap is otherwise padded with - the caller hands in the
+ * chunk-level work (loads of a later chunk, the stores of the previous one, pointer arithmetic) one
+ * instruction at a time, see run_block */
+template <int BITS, bool EMIT, int FORMAT = kWide, typename Fill = NoFill>
 __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C, const int32_t *x, int32_t xn0,
-                                                    const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq)
+                                                    const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq, Fill fill = Fill())
 {
   auto sample = [&](int k) -> int32_t { /* sample k of this chunk (k = 16: first of the next), k compile-time */
     if (FORMAT == kPairs) {
@@ -242,6 +251,7 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
       sqw = (uint32_t)qd * (uint32_t)qd;
       pin(sqw);
     }
+    fill(jc);
     s += quad_dpp<kEncTM ? kDppRowRor4 : 0xB1>(s);
     pin(s);
     if (EMIT) {
@@ -493,15 +503,18 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
        * half of every dword as well; the last full chunk of a stream that ends on a chunk boundary
        * is left to the tail loop - its channel-1 load would read two bytes past the stream. */
       constexpr int FMT = CHF == 1 ? kPairs : kFrames;
+      constexpr int kParts = CHF == 1 ? 2 : 4; /* 16-byte loads per chunk */
       struct Raw { /* one chunk as loaded: 32 (mono) / 64 (stereo) bytes */
         uint32_t d[CHF == 1 ? 8 : 16];
+        __device__ __forceinline__ void load_part(const int16_t *x, int k) /* k compile-time after unrolling */
+        {
+          const u32x4 a = reinterpret_cast<const U32x4 *>(x + 8 * k)->v;
+          d[4 * k] = a.x; d[4 * k + 1] = a.y; d[4 * k + 2] = a.z; d[4 * k + 3] = a.w;
+        }
         __device__ __forceinline__ void load(const int16_t *x)
         {
 #pragma unroll
-          for (int k = 0; k < (CHF == 1 ? 2 : 4); k++) {
-            const u32x4 a = reinterpret_cast<const U32x4 *>(x + 8 * k)->v;
-            d[4 * k] = a.x; d[4 * k + 1] = a.y; d[4 * k + 2] = a.z; d[4 * k + 3] = a.w;
-          }
+          for (int k = 0; k < kParts; k++) load_part(x, k);
         }
       };
       uint32_t chunks = full;
@@ -516,19 +529,65 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         b0.load(rp);
         if (chunks > 1) rp += (uint64_t)kChunk * ch;
         b1.load(rp);
+        if (chunks > 2) rp += (uint64_t)kChunk * ch; /* rp: where chunk min(2, chunks - 1) starts - what the first chunk prefetches */
         encode_prime_quad<BITS>(L, C, (int32_t)(int16_t)b0.d[0], lds); /* both formats: sample 0 is the low half of dword 0 */
       }
+      /* The chunk-level work rides in the first DPP gap of the samples (see encode_chunk16_quad): the
+       * loads of chunk k+2 in samples 0-3, then - stereo 4-bit, the BASELINE shape - the store of chunk
+       * k-1's codes taken apart into its seven instructions, then the prefetch pointer.  Every tap of
+       * a quad (and both roles of the dual mapping) holds the same codes and stores the same bytes to
+       * the same address: no exec-masked block, no branch.  Other shapes keep the one-piece store. */
+      constexpr bool kStaged = EMIT && kEncTM && CHF == 2 && BITS == 4;
+      uint32_t wp0 = 0, wp1 = 0;          /* the previous chunk's code words */
+      uint32_t st_send = 0, st_keep = 0, st_recv = 0, st_x = 0, st_y = 0;
+      uint8_t *sp = body + 8u * c;        /* where this lane's half of the previous chunk's 16 bytes goes */
+      /* A = channel 0's word, B = channel 1's: lane c holds (keep, recv) = c ? (B.., A..) : (A.., B..), so the
+       * byte selectors of store_chunk_codes get their source halves swapped on the channel-1 lane */
+      const uint32_t sel_x = c ? (0x02060307u ^ 0x04040404u) : 0x02060307u, sel_y = c ? (0x00040105u ^ 0x04040404u) : 0x00040105u;
       auto one = [&](uint32_t k, const Raw &cur, const Raw &ahead, Raw &incoming) {
-        if (k + 2 < chunks) rp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
-        incoming.load(rp);
         uint32_t w[2] = {0, 0};
-        encode_chunk16_quad<BITS, EMIT, FMT>(L, C, reinterpret_cast<const int32_t *>(cur.d), (int32_t)ahead.d[0], lds, w, last_qd, sq);
-        if (EMIT && writer) store_chunk_codes<BITS, CHF, QUAD && !kEncTM>(body + (uint64_t)k * kOutStride * ch, w, c);
+        const bool pending = kStaged && k != 0;
+        auto fill = [&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (j < kParts) incoming.load_part(rp, j); /* prefetch chunk k+2 (clamped to the last full one) */
+          if constexpr (kStaged) {
+            /* lane c writes bytes 8c..8c+7 of the pair's sixteen: a0 b0 a1 b1 | a2 b2 a3 b3 of word c of both
+             * channels; it has its own word c and needs the partner's */
+            if constexpr (j == 4) { st_send = c ? wp0 : wp1; pin(st_send); }
+            if constexpr (j == 5) { st_keep = c ? wp1 : wp0; pin(st_keep); }
+            if constexpr (j == 6) { st_recv = pair_swap<false>(st_send, c); pin(st_recv); }
+            if constexpr (j == 7) { st_x = perm(st_keep, st_recv, sel_x); pin(st_x); }
+            if constexpr (j == 8) { st_y = perm(st_keep, st_recv, sel_y); pin(st_y); }
+            if constexpr (j == 9) { /* unconditional: in chunk 0 it puts zeros where chunk 0's own codes land one chunk later */
+              u32x2 v;
+              v.x = st_x;
+              v.y = st_y;
+              reinterpret_cast<U32x2 *>(sp)->v = v;
+            }
+            if constexpr (j == 10) sp += pending ? kOutStride * 2 : 0u;
+          }
+          if constexpr (j == 12) {
+            if (k + 3 < chunks) rp += (uint64_t)kChunk * ch; /* for the next chunk's prefetch */
+          }
+        };
+        encode_chunk16_quad<BITS, EMIT, FMT>(L, C, reinterpret_cast<const int32_t *>(cur.d), (int32_t)ahead.d[0], lds, w, last_qd, sq, fill);
+        if constexpr (kStaged) {
+          wp0 = w[0];
+          wp1 = w[1];
+        } else {
+          if (EMIT && writer) store_chunk_codes<BITS, CHF, QUAD && !kEncTM>(body + (uint64_t)k * kOutStride * ch, w, c);
+        }
       };
       for (uint32_t k = 0; k < chunks; k += 3) {
         one(k, b0, b1, b2);
         if (k + 1 < chunks) one(k + 1, b1, b2, b0);
         if (k + 2 < chunks) one(k + 2, b2, b0, b1);
+      }
+      if constexpr (kStaged) { /* the last chunk's codes */
+        if (chunks) {
+          const uint32_t w[2] = {wp0, wp1};
+          store_chunk_codes<BITS, CHF, false>(body + (uint64_t)(chunks - 1) * kOutStride * ch, w, c);
+        }
       }
       done = chunks * kChunk;
     } else if constexpr (QUAD) {
