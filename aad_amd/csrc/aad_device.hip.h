@@ -92,7 +92,8 @@ constexpr int kLdsStepOff = 0, kLdsHrOff = 1024, kLdsHsOff = 2048;
 constexpr int kLdsCodeOff = 3072;
 constexpr int kLdsCodeShift = 3; /* log2 of the record size */
 constexpr int kLdsDeltaOff = kLdsCodeOff + (16 << kLdsCodeShift);
-constexpr int kLdsBytes = kLdsDeltaOff + 16;
+constexpr int kLdsDelta4Off = kLdsDeltaOff + 16; /* the same eight deltas times kIdxScale (encoders' scaled step index) */
+constexpr int kLdsBytes = kLdsDelta4Off + 16;
 /* Quad kernels only: the same three values as 16-byte records {step, hr, hs, -}, addressed by
  * idxb & 0xFF0 - one instruction less than slot_addr and one lookup instead of two.  A wave of
  * the quad mapping holds just 16 distinct recurrences, so the 8-bank-group stride that made this
@@ -236,7 +237,10 @@ __device__ __forceinline__ void stage_tables(char *lds)
     e.y = ((uint32_t)(int32_t)dt[mag] & 0xFFFFu) | ((neg ? (1u << kShift) - 1u : 0u) << 16);
     *reinterpret_cast<u32x2 *>(lds + kLdsCodeOff + (code << kLdsCodeShift)) = e;
   }
-  if (threadIdx.x < 8) reinterpret_cast<int16_t *>(lds + kLdsDeltaOff)[threadIdx.x] = dt[threadIdx.x & ((1 << kShift) - 1)];
+  if (threadIdx.x < 8) {
+    reinterpret_cast<int16_t *>(lds + kLdsDeltaOff)[threadIdx.x] = dt[threadIdx.x & ((1 << kShift) - 1)];
+    reinterpret_cast<int16_t *>(lds + kLdsDelta4Off)[threadIdx.x] = (int16_t)(4 * dt[threadIdx.x & ((1 << kShift) - 1)]);
+  }
   __syncthreads();
 }
 

@@ -103,10 +103,15 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     if (PACKED) return (k & 1) ? x[k >> 1] >> 16 : (int32_t)(int16_t)x[k >> 1];
     return x[k];
   };
-  uint32_t sa = slot_addr(L.idxb);
-  uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
-  float hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
-  float hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
+  /* The step record {2 step, hr, hs} comes from the four-copy wide table with ONE lookup at an address
+   * that is one v_and_or_b32 of the scaled step index (see wide4_addr) - the three dense dword arrays
+   * cost two address instructions and three lookups per sample.  Bank conflicts between lanes are the
+   * price (a 96-bit read is served eight lanes per cycle; two lanes with the same copy collide when
+   * their slots have the same parity); with the waves a chip-filling batch keeps on every SIMD that
+   * latency is covered, and the dense mapping is only used for such batches. */
+  int32_t idxj = L.idxb * kIdxScale;
+  const uint32_t copy = (threadIdx.x & 3u) << 4;
+  u32x3 e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide4_addr(idxj, copy));
   int32_t p = predict(L);
   int32_t d = sample(0) - p;
   int32_t m = d >> 31;
@@ -114,12 +119,13 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
   static_for<0, kChunk>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     /* A */
-    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), hs, hr), Pack<BITS>::kMagMax);
+    const uint32_t step2 = e.x; /* 2 * step (stage_tables<.., WIDE_STEP_SHIFT = 1>) */
+    const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)), Pack<BITS>::kMagMax);
     const uint32_t m21 = (mag << 1) | 1u;
-    const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDeltaOff - 1) + m21);
+    const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDelta4Off - 1) + m21); /* 4 * delta */
     __builtin_amdgcn_sched_barrier(0);
     /* B */
-    const int32_t q = (int32_t)(__umul24(step, m21) >> (BITS - 1));
+    const int32_t q = (int32_t)(__umul24(step2, m21) >> BITS); /* (step * (2 mag + 1)) >> (BITS - 1) */
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
     lms_first(L, qd);
@@ -135,13 +141,8 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     pin_weights(L);
     __builtin_amdgcn_sched_barrier(0);
     /* C */
-    L.idxb = clamp_idx(L.idxb + delta);
-    if (j + 1 < kChunk) {
-      sa = slot_addr(L.idxb);
-      step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + sa);
-      hr = *reinterpret_cast<const float *>(lds + kLdsHrOff + sa);
-      hs = *reinterpret_cast<const float *>(lds + kLdsHsOff + sa);
-    }
+    idxj = min(max(idxj + delta, kIdxScale * kIdxMin), kIdxScale * kIdxMax);
+    if (j + 1 < kChunk) e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide4_addr(idxj, copy));
     __builtin_amdgcn_sched_barrier(0);
     /* D */
     lms_rest_and_shift(L, qd, y);
@@ -158,6 +159,7 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     }
     __builtin_amdgcn_sched_barrier(0);
   });
+  L.idxb = idxj >> 2; /* kIdxScale = 4 */
 }
 
 /*
@@ -547,10 +549,14 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
       auto one = [&](uint32_t k, const Raw &cur, const Raw &ahead, Raw &incoming) {
         uint32_t w[2] = {0, 0};
         const bool pending = kStaged && k != 0;
+        if constexpr (!kStaged) { /* (the other shapes ran 1-3 % slower with their loads in the gaps: measured, same box) */
+          incoming.load(rp); /* prefetch chunk k+2 (clamped to the last full one) */
+          if (k + 3 < chunks) rp += (uint64_t)kChunk * ch;
+        }
         auto fill = [&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          if constexpr (j < kParts) incoming.load_part(rp, j); /* prefetch chunk k+2 (clamped to the last full one) */
           if constexpr (kStaged) {
+            if constexpr (j < kParts) incoming.load_part(rp, j); /* prefetch chunk k+2 (clamped to the last full one) */
             /* lane c writes bytes 8c..8c+7 of the pair's sixteen: a0 b0 a1 b1 | a2 b2 a3 b3 of word c of both
              * channels; it has its own word c and needs the partner's */
             if constexpr (j == 4) { st_send = c ? wp0 : wp1; pin(st_send); }
@@ -565,9 +571,9 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
               reinterpret_cast<U32x2 *>(sp)->v = v;
             }
             if constexpr (j == 10) sp += pending ? kOutStride * 2 : 0u;
-          }
-          if constexpr (j == 12) {
-            if (k + 3 < chunks) rp += (uint64_t)kChunk * ch; /* for the next chunk's prefetch */
+            if constexpr (j == 12) {
+              if (k + 3 < chunks) rp += (uint64_t)kChunk * ch; /* for the next chunk's prefetch */
+            }
           }
         };
         encode_chunk16_quad<BITS, EMIT, FMT>(L, C, reinterpret_cast<const int32_t *>(cur.d), (int32_t)ahead.d[0], lds, w, last_qd, sq, fill);
@@ -789,9 +795,9 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
-  __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuadEnc : kLdsBytes];
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytesQuadEnc]; /* dense and quad encoders share the four-copy wide table */
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
-  stage_tables<BITS, QUAD, 1, QUAD>(lds);
+  stage_tables<BITS, true, 1, true>(lds);
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   const uint32_t ch = CHF ? CHF : a.channels;
