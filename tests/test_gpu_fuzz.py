@@ -23,8 +23,11 @@ def engine():
     e.close()
 
 
+SEEDS = int(os.environ.get("AAD_FUZZ_SEEDS", "8"))  # a one-off deeper run: AAD_FUZZ_SEEDS=200 pytest -m gpu tests/test_gpu_fuzz.py
+
+
 @pytest.mark.parametrize("mapping", ["dense", "quad", "quad-fused", "auto"])
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(SEEDS))
 def test_random_parameter_sets(engine, mapping, seed):
     rng = np.random.default_rng(1000 + seed)
     engine.set_mapping(mapping)
@@ -55,5 +58,75 @@ def test_random_parameter_sets(engine, mapping, seed):
             decoded = engine.decode_host(images)
             for i, (got, w) in enumerate(zip(decoded, want)):
                 assert np.array_equal(got, ob.decode(w)[0]), (seed, mapping, ch, bits, ms, trials, mbs, lengths[i])
+    finally:
+        engine.set_mapping("auto")
+
+
+@pytest.mark.parametrize("mapping", ["dense", "quad", "quad-fused"])
+@pytest.mark.parametrize("seed", range(max(4, SEEDS // 2)))
+def test_random_device_resident_plans(engine, mapping, seed):
+    """Device-resident plans with hand-made stream tables: uniform layouts at odd alignments (the
+    table-free kernel path, the dense decoder's 16-frame lead chunk, streamed stores on and off) and
+    shuffled non-uniform ones, multi-block streams included - against the oracle."""
+    import torch
+    from aad_amd.capi import STREAM_DESC_DTYPE
+    from aad_amd.engine import parse_header
+    rng = np.random.default_rng(5000 + seed)
+    engine.set_mapping(mapping)
+    try:
+        for _ in range(3):
+            ch = int(rng.choice([1, 2, 2, 2]))
+            bits = int(rng.choice([4, 4, 3, 2]))
+            ms = bool(ch == 2 and rng.integers(0, 4) == 0)
+            trials = int(rng.choice([0, 0, 0, 1, 2]))
+            mbs = int(rng.choice([1024, 1024, 256, 700]))
+            rc, block_size, spb = ob.geometry(mbs, ch, bits)
+            assert rc == 0
+            streams = int(rng.integers(1, 40))
+            uniform = bool(rng.integers(0, 2))
+            n0 = int(rng.integers(1, 3 * spb + 20))
+            lengths = [n0] * streams if uniform else [int(rng.integers(1, 3 * spb + 20)) for _ in range(streams)]
+            pcms = [synth_pcm(1, n, ch, seed=int(rng.integers(0, 1 << 30)), kind=str(rng.choice(["music", "noise"])))[0] for n in lengths]
+            param = make_parameter(ch, bits, mbs, 48000, ms, trials)
+            sizes = [engine.encoded_size(param, n) for n in lengths]
+            # layout: a leading pad of 0..63 int16 / bytes, then streams back to back at a pitch of
+            # the (padded) maximum for uniform batches, in shuffled order otherwise
+            pad_pcm, pad_dat = int(rng.integers(0, 64)), int(rng.integers(0, 64))
+            pitch_pcm = (max(lengths) * ch + int(rng.integers(0, 9))) if uniform else None
+            pitch_dat = (max(sizes) + int(rng.integers(0, 17))) if uniform else None
+            order = list(range(streams)) if uniform else list(rng.permutation(streams))
+            d = np.zeros(streams, dtype=STREAM_DESC_DTYPE)
+            pos_p, pos_d = pad_pcm, pad_dat
+            for slot in order:
+                d["pcm_offset"][slot], d["data_offset"][slot] = pos_p, pos_d
+                d["data_size"][slot], d["num_samples"][slot] = sizes[slot], lengths[slot]
+                pos_p += pitch_pcm if uniform else lengths[slot] * ch + int(rng.integers(0, 5))
+                pos_d += pitch_dat if uniform else sizes[slot] + int(rng.integers(0, 7))
+            flat = np.zeros(pos_p + 64, dtype=np.int16)
+            for i, p in enumerate(pcms):
+                o = int(d["pcm_offset"][i])
+                flat[o:o + p.size] = p.reshape(-1)
+            d_pcm = torch.from_numpy(flat).cuda()
+            d_img = torch.zeros(pos_d + 64, dtype=torch.uint8, device="cuda")
+            plan = engine.encode_plan(param, d)
+            plan.run(d_pcm, d_img, None)
+            torch.cuda.synchronize()
+            plan.close()
+            img = d_img.cpu().numpy()
+            want = [ob.encode(p, bits, mbs, 48000, ms, trials) for p in pcms]
+            for i, w in enumerate(want):
+                o = int(d["data_offset"][i])
+                assert bytes(img[o:o + len(w)]) == w, (seed, mapping, "encode", i, ch, bits, ms, trials, mbs, lengths[i], uniform)
+            hd = parse_header(want[0][:31])
+            dplan = engine.decode_plan(hd, d, True)
+            d_out = torch.zeros_like(d_pcm)
+            dplan.run(d_img, d_out)
+            torch.cuda.synchronize()
+            dplan.close()
+            out = d_out.cpu().numpy()
+            for i, w in enumerate(want):
+                o = int(d["pcm_offset"][i])
+                ref = ob.decode(w)[0].reshape(-1)
+                assert np.array_equal(out[o:o + ref.size], ref), (seed, mapping, "decode", i, ch, bits, ms, trials, mbs, lengths[i], uniform)
     finally:
         engine.set_mapping("auto")
