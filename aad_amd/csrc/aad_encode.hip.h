@@ -306,6 +306,11 @@ struct EncodeArgs {
   uint32_t mid_side;
   uint32_t trials;
   uint32_t bits;
+  /* Frames at the head of every stream that are context only (0, or one block): encoding starts
+   * behind them, the image holds the rest.  The trial search looks one block back in the INPUT
+   * (reference src/aad_encoder.c:503-512), so a stream continued from carried state has to bring
+   * that block along. */
+  uint32_t lead_frames;
   UniformLayout uni;
   uint8_t header_template[32]; /* 31-byte file header with num_samples = 0 */
 };
@@ -833,15 +838,16 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
   }
 
   if (c == 0 && writer) { /* file header - reference src/aad_encoder.c:190-214 */
+    const uint32_t encoded = total - a.lead_frames;
     for (int i = 0; i < kFileHeaderBytes; i++) out[i] = a.header_template[i];
-    out[14] = (uint8_t)(total >> 24);
-    out[15] = (uint8_t)(total >> 16);
-    out[16] = (uint8_t)(total >> 8);
-    out[17] = (uint8_t)total;
+    out[14] = (uint8_t)(encoded >> 24);
+    out[15] = (uint8_t)(encoded >> 16);
+    out[16] = (uint8_t)(encoded >> 8);
+    out[17] = (uint8_t)encoded;
   }
 
   uint64_t block_off = kFileHeaderBytes;
-  for (uint64_t first = 0; first < total; first += spb, block_off += a.block_size) {
+  for (uint64_t first = a.lead_frames; first < total; first += spb, block_off += a.block_size) {
     const uint32_t n = total - first < spb ? (uint32_t)(total - first) : spb;
     S L;
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);

@@ -10,7 +10,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/aad_hip.h"
@@ -35,6 +40,20 @@ struct Staging {
   size_t cap = 0;
 };
 
+/* A few helper threads that only ever memcpy: the staging copies between the caller's pageable buffers
+ * and the pinned blocks are the slowest stage of the host-memory path (one core moves ~10 GB/s, PCIe
+ * ~50 GB/s), so chunks of a megabyte and more are filled and drained by up to four threads, each on a
+ * contiguous range of streams.  Started at a context's first such chunk, joined in ContextDestroy; no
+ * HIP call is ever made from them. */
+struct StagingPool {
+  std::vector<std::thread> threads;
+  std::mutex lock;
+  std::condition_variable work, done;
+  std::function<void(unsigned)> job;
+  unsigned generation = 0, pending = 0;
+  bool stop = false;
+};
+
 struct AADHipContext {
   int device;
   hipStream_t stream;
@@ -44,7 +63,11 @@ struct AADHipContext {
    * host fills chunk k+1's input block and drains chunk k-1's output block */
   Staging in[2], out[2];
   hipEvent_t chunk_done[2];
-  bool have_events;
+  /* a cut batch runs its copies on streams of their own, so that tile k+1 goes up and tile k-1
+   * comes down while tile k computes */
+  hipStream_t up_stream, down_stream;
+  hipEvent_t uploaded[2], computed[2];
+  bool have_events, have_pipeline;
   /* device-only scratch of the reconstruction modes (the .aad images never leave HBM) */
   void *d_scratch;
   size_t scratch_capacity;
@@ -55,6 +78,11 @@ struct AADHipContext {
   /* AADHip_ContextSetOption; the defaults come from the environment ONCE, at creation */
   int32_t lane_mapping; /* enum AADHipLaneMapping */
   int32_t trial_lanes;  /* enum AADHipTrialLanes */
+  int64_t tile_bytes;      /* 0 = the built-in tile budget of the host-memory path, else that many bytes */
+  void *d_state;           /* predictor states of a group of streams between its tiles (host-memory encode) */
+  size_t state_capacity;   /* in records */
+  int32_t staging_threads; /* 0 = by core count, else the number of threads that copy (1 = the caller alone) */
+  StagingPool *pool;    /* staging helper threads, created on demand */
 };
 
 struct AADHipEncodePlan {
@@ -318,8 +346,10 @@ void launch_decode(const AADHipContext *ctx, const aad::DecodeArgs &a, int32_t *
  * calls put the tables into the block that carries the payload instead. */
 namespace {
 
+/* lead_frames: context frames at the head of every stream (EncodeArgs::lead_frames) - 0, or one block */
 AADApiResult encode_plan_init(const struct AADEncodeParameter *parameter, uint32_t num_streams,
-                              const struct AADHipStreamDesc *streams, aad::EncodeArgs *args)
+                              const struct AADHipStreamDesc *streams, aad::EncodeArgs *args, uint32_t lead_frames = 0,
+                              bool streams_checked = false)
 {
   AADHeaderInfo h;
   if (AADFormat_ParameterToHeader(parameter, 1, AAD_HIP_MAX_NUM_CHANNELS, &h) != AAD_APIRESULT_OK)
@@ -327,9 +357,9 @@ AADApiResult encode_plan_init(const struct AADEncodeParameter *parameter, uint32
   /* what AADEncoder_EncodeHeader would reject (bits == 1, zero rate, M/S on mono, ...) */
   if (!AADFormat_HeaderFieldsValid(&h, AAD_HIP_MAX_NUM_CHANNELS)) return AAD_APIRESULT_INVALID_FORMAT;
   if (h.ch_process_method == AAD_CH_PROCESS_METHOD_MS && h.num_channels != 2) return AAD_APIRESULT_INVALID_FORMAT;
-  for (uint32_t i = 0; i < num_streams; i++) {
-    if (streams[i].num_samples == 0) return AAD_APIRESULT_INVALID_FORMAT; /* src/aad_encoder.c:157-159 */
-    h.num_samples = streams[i].num_samples;
+  for (uint32_t i = 0; !streams_checked && i < num_streams; i++) {
+    if (streams[i].num_samples <= lead_frames) return AAD_APIRESULT_INVALID_FORMAT; /* src/aad_encoder.c:157-159 */
+    h.num_samples = streams[i].num_samples - lead_frames;
     if (streams[i].data_size < AADFormat_EncodedSize(&h)) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
   }
   memset(args, 0, sizeof(*args));
@@ -339,6 +369,7 @@ AADApiResult encode_plan_init(const struct AADEncodeParameter *parameter, uint32
   args->samples_per_block = h.num_samples_per_block;
   args->mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
   args->trials = parameter->num_encode_trials;
+  args->lead_frames = lead_frames;
   args->uni = detect_uniform(num_streams, streams);
   h.num_samples = 0;
   AADFormat_PutHeader(&h, args->header_template);
@@ -347,8 +378,11 @@ AADApiResult encode_plan_init(const struct AADEncodeParameter *parameter, uint32
 }
 
 /* prefix: num_streams + 1 entries, the exclusive prefix sum of blocks per stream */
+/* known_blocks: per-stream block counts of streams that an earlier call of this function has already
+ * validated (the tiles of the host-memory path) - the checks and their divisions are skipped */
 AADApiResult decode_plan_init(const struct AADHeaderInfo *format, int32_t has_file_header, uint32_t num_streams,
-                              const struct AADHipStreamDesc *streams, uint64_t *prefix, aad::DecodeArgs *args)
+                              const struct AADHipStreamDesc *streams, uint64_t *prefix, aad::DecodeArgs *args,
+                              const uint64_t *known_blocks = nullptr)
 {
   AADHeaderInfo h = *format;
   h.num_samples = 1; /* per-stream counts come from the table */
@@ -356,7 +390,11 @@ AADApiResult decode_plan_init(const struct AADHeaderInfo *format, int32_t has_fi
   if (h.ch_process_method == AAD_CH_PROCESS_METHOD_MS && h.num_channels != 2) return AAD_APIRESULT_INVALID_FORMAT;
   uint64_t blocks = 0;
   const uint32_t head = has_file_header ? AAD_HEADER_SIZE : 0;
-  for (uint32_t i = 0; i < num_streams; i++) {
+  for (uint32_t i = 0; known_blocks != nullptr && i < num_streams; i++) {
+    prefix[i] = blocks;
+    blocks += known_blocks[i];
+  }
+  for (uint32_t i = 0; known_blocks == nullptr && i < num_streams; i++) {
     prefix[i] = blocks;
     /* per-block loop counters on the device are 32-bit: a header that claims a block of 2^31
      * samples and more (nothing in the reference's checks forbids it) is refused here */
@@ -445,6 +483,20 @@ AADApiResult run_decode(AADHipContext *ctx, const aad::DecodeArgs &a)
   return hip_ok(ctx, hipGetLastError(), "decode launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
 }
 
+void staging_pool_stop(AADHipContext *ctx)
+{
+  StagingPool *p = ctx->pool;
+  if (p == nullptr) return;
+  {
+    std::lock_guard<std::mutex> g(p->lock);
+    p->stop = true;
+  }
+  p->work.notify_all();
+  for (auto &t : p->threads) t.join();
+  delete p;
+  ctx->pool = nullptr;
+}
+
 int32_t option_from_env(const char *name, const char *const *words, int32_t count)
 {
   const char *e = getenv(name);
@@ -480,10 +532,16 @@ AADApiResult AADHip_ContextCreate(int32_t device_index, void *hip_stream, struct
   ctx->owns_stream = false;
   ctx->last_error[0] = 0;
   ctx->have_events = false;
+  ctx->have_pipeline = false;
   ctx->d_scratch = nullptr;
   ctx->scratch_capacity = 0;
   ctx->d_residual = nullptr;
   ctx->residual_capacity = 0;
+  ctx->pool = nullptr;
+  ctx->staging_threads = 0;
+  ctx->tile_bytes = 0;
+  ctx->d_state = nullptr;
+  ctx->state_capacity = 0;
   /* the environment is consulted here (and when the legacy API takes a parked context back into
    * use), never on a launch path */
   AADHipInternal_ContextOptionsFromEnvironment(ctx);
@@ -506,6 +564,7 @@ AADApiResult AADHip_ContextCreate(int32_t device_index, void *hip_stream, struct
 void AADHip_ContextDestroy(struct AADHipContext *ctx)
 {
   if (ctx == nullptr) return;
+  staging_pool_stop(ctx);
   {
     DeviceGuard guard(ctx);
     if (guard.ok) {
@@ -514,9 +573,18 @@ void AADHip_ContextDestroy(struct AADHipContext *ctx)
         staging_release(ctx->in[b]);
         staging_release(ctx->out[b]);
         if (ctx->have_events) (void)hipEventDestroy(ctx->chunk_done[b]);
+        if (ctx->have_pipeline) {
+          (void)hipEventDestroy(ctx->uploaded[b]);
+          (void)hipEventDestroy(ctx->computed[b]);
+        }
+      }
+      if (ctx->have_pipeline) {
+        (void)hipStreamDestroy(ctx->up_stream);
+        (void)hipStreamDestroy(ctx->down_stream);
       }
       if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
       if (ctx->d_residual) (void)hipFree(ctx->d_residual);
+      if (ctx->d_state) (void)hipFree(ctx->d_state);
       if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     }
   }
@@ -539,6 +607,13 @@ void AADHipInternal_ContextOptionsFromEnvironment(struct AADHipContext *ctx)
   static const char *const kTrialLanes[] = {"dual", "single"};
   ctx->lane_mapping = option_from_env("AAD_HIP_MAPPING", kMappings, 4);
   ctx->trial_lanes = option_from_env("AAD_HIP_TRIAL_LANES", kTrialLanes, 2);
+  const char *threads = getenv("AAD_HIP_STAGING_THREADS");
+  if (threads != nullptr && threads[0] >= '1' && threads[0] <= '8' && threads[1] == '\0') ctx->staging_threads = threads[0] - '0';
+  const char *tile = getenv("AAD_HIP_TILE_KBYTES");
+  if (tile != nullptr) {
+    const long long v = atoll(tile);
+    if (v > 0 && v <= 0x7FFFFFFF) ctx->tile_bytes = (int64_t)v << 10;
+  }
 }
 
 int32_t AADHipInternal_ContextDevice(const struct AADHipContext *ctx) { return ctx->device; }
@@ -554,6 +629,14 @@ AADApiResult AADHip_ContextSetOption(struct AADHipContext *ctx, int32_t option, 
     case AAD_HIP_OPTION_TRIAL_LANES:
       if (value != AAD_HIP_TRIAL_LANES_DUAL && value != AAD_HIP_TRIAL_LANES_SINGLE) return AAD_APIRESULT_INVALID_ARGUMENT;
       ctx->trial_lanes = value;
+      return AAD_APIRESULT_OK;
+    case AAD_HIP_OPTION_STAGING_THREADS:
+      if (value < 0 || value > 8) return AAD_APIRESULT_INVALID_ARGUMENT;
+      ctx->staging_threads = value;
+      return AAD_APIRESULT_OK;
+    case AAD_HIP_OPTION_TILE_KBYTES:
+      if (value < 0) return AAD_APIRESULT_INVALID_ARGUMENT;
+      ctx->tile_bytes = (int64_t)value << 10;
       return AAD_APIRESULT_OK;
     default:
       return AAD_APIRESULT_INVALID_ARGUMENT;
@@ -702,8 +785,84 @@ namespace {
 
 uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
-constexpr uint64_t kChunkBudget = 8ull << 20; /* payload bytes (in + out) per chunk of a cut batch */
-constexpr uint64_t kCutAbove = 2 * kChunkBudget;
+constexpr uint64_t kChunkBudget = 16ull << 20; /* payload bytes (in + out) per tile of a cut batch */
+constexpr uint64_t kCutAbove = kChunkBudget;
+
+constexpr uint64_t kParallelStagingAbove = 1ull << 20; /* bytes in a chunk from which the helper threads pay */
+
+unsigned staging_threads(const AADHipContext *ctx)
+{
+  if (ctx->staging_threads > 0) return (unsigned)ctx->staging_threads;
+  static const unsigned hw = std::thread::hardware_concurrency(); /* asked once: it reads /sys */
+  return hw >= 8 ? 4u : (hw >= 4 ? 2u : 1u);
+}
+
+void staging_pool_main(StagingPool *p, unsigned index)
+{
+  unsigned seen = 0;
+  for (;;) {
+    std::function<void(unsigned)> job;
+    {
+      std::unique_lock<std::mutex> g(p->lock);
+      p->work.wait(g, [&] { return p->stop || p->generation != seen; });
+      if (p->stop) return;
+      seen = p->generation;
+      job = p->job;
+    }
+    job(index);
+    {
+      std::lock_guard<std::mutex> g(p->lock);
+      if (--p->pending == 0) p->done.notify_one();
+    }
+  }
+}
+
+/* Run body(first, last) over [0, count) cut into contiguous ranges of about equal cost, one per thread
+ * (the caller's included).  `prefix` has count + 1 entries: the running cost. */
+template <class Body>
+void staged_ranges(AADHipContext *ctx, uint32_t count, const std::vector<uint64_t> &prefix, Body body)
+{
+  const unsigned want = count < 2 || prefix[count] < kParallelStagingAbove ? 1u : staging_threads(ctx);
+  if (want <= 1) {
+    body(0u, count);
+    return;
+  }
+  if (ctx->pool != nullptr && ctx->pool->threads.size() + 1 != want) staging_pool_stop(ctx);
+  if (ctx->pool == nullptr) {
+    ctx->pool = new (std::nothrow) StagingPool();
+    if (ctx->pool == nullptr) {
+      body(0u, count);
+      return;
+    }
+    for (unsigned t = 1; t < want; t++) ctx->pool->threads.emplace_back(staging_pool_main, ctx->pool, t);
+  }
+  StagingPool *p = ctx->pool;
+  const unsigned parts = (unsigned)p->threads.size() + 1;
+  auto bound = [&](unsigned t) -> uint32_t { /* first item of part t */
+    if (t >= parts) return count;
+    const uint64_t target = prefix[count] / parts * t;
+    uint32_t lo = 0, hi = count;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (prefix[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  auto part = [&](unsigned t) {
+    const uint32_t a = bound(t), b = bound(t + 1);
+    if (b > a) body(a, b);
+  };
+  {
+    std::lock_guard<std::mutex> g(p->lock);
+    p->job = part;
+    p->pending = parts - 1;
+    p->generation++;
+  }
+  p->work.notify_all();
+  part(0);
+  std::unique_lock<std::mutex> g(p->lock);
+  p->done.wait(g, [&] { return p->pending == 0; });
+}
 
 bool ensure_events(AADHipContext *ctx)
 {
@@ -717,129 +876,334 @@ bool ensure_events(AADHipContext *ctx)
   return true;
 }
 
-/* [first, last) stream ranges whose payload stays within the budget (at least one stream each) */
-struct ChunkCutter {
-  uint64_t budget;
-  uint32_t n, pos = 0;
-  ChunkCutter(uint64_t total_bytes, uint32_t num_streams) : budget(total_bytes > kCutAbove ? kChunkBudget : ~0ull), n(num_streams) {}
-  template <class Cost>
-  bool next(Cost cost, uint32_t *first, uint32_t *last)
+/* the copy streams and their events: made at a context's first cut batch (a process that only ever
+ * sends small calls keeps one stream - every extra one costs the runtime a little on each call) */
+bool ensure_pipeline(AADHipContext *ctx)
+{
+  if (ctx->have_pipeline) return true;
+  hipEvent_t ev[4];
+  int made = 0;
+  for (; made < 4; made++)
+    if (!hip_ok(ctx, hipEventCreateWithFlags(&ev[made], hipEventDisableTiming), "hipEventCreate")) break;
+  bool ok = made == 4;
+  if (ok && !hip_ok(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking), "hipStreamCreate")) ok = false;
+  if (ok && !hip_ok(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking), "hipStreamCreate")) {
+    (void)hipStreamDestroy(ctx->up_stream);
+    ok = false;
+  }
+  if (!ok) {
+    for (int i = 0; i < made; i++) (void)hipEventDestroy(ev[i]);
+    return false;
+  }
+  for (int b = 0; b < 2; b++) {
+    ctx->uploaded[b] = ev[b];
+    ctx->computed[b] = ev[2 + b];
+  }
+  ctx->have_pipeline = true;
+  return true;
+}
+
+/* the streams a tile's three stages run on: all the context's own for a batch that goes as one
+ * tile (no cross-stream hop on the latency path of small calls), three different ones for a cut batch */
+struct Route {
+  hipStream_t up, run, down;
+};
+
+Route route_for(const AADHipContext *ctx, bool piped)
+{
+  if (piped) return {ctx->up_stream, ctx->stream, ctx->down_stream};
+  return {ctx->stream, ctx->stream, ctx->stream};
+}
+
+/* make `to` wait for what `from` holds so far */
+bool hop(AADHipContext *ctx, hipEvent_t event, hipStream_t from, hipStream_t to)
+{
+  if (from == to) return true;
+  return hip_ok(ctx, hipEventRecord(event, from), "hipEventRecord") &&
+         hip_ok(ctx, hipStreamWaitEvent(to, event, 0), "hipStreamWaitEvent");
+}
+
+void settle(const Route &r)
+{
+  (void)hipStreamSynchronize(r.up);
+  (void)hipStreamSynchronize(r.run);
+  (void)hipStreamSynchronize(r.down);
+}
+
+/*
+ * How a batch is cut.  A stream's blocks are chained in the encoder (block k starts from the
+ * predictor block k-1 left behind), so one launch costs about `blocks per stream` x 64 us however
+ * few streams it holds: cutting a batch of long streams BY STREAM would pay that chain once per cut.
+ * The batch is therefore cut both ways: consecutive streams form a GROUP until one block of each
+ * fills the tile budget, and a group is walked in TILES of `budget / (streams alive x block bytes)`
+ * blocks of every stream at once, the predictor state staying on the device between tiles (encode;
+ * decode blocks are independent and only share the tiling).  Inside a group streams are ordered
+ * longest first, so that the streams still alive at any block are a prefix of that order and a
+ * stream's state record keeps its index for the whole group.
+ */
+struct TileStep {
+  uint32_t alive;          /* streams in the tile: order[0 .. alive) */
+  uint64_t block0, block1; /* blocks [block0, block1) of each */
+  bool group_first, group_last;
+};
+
+struct TilePlanner {
+  const uint64_t *blocks; /* per stream: blocks to walk (0 = nothing to do) */
+  uint32_t n;
+  uint64_t block_cost, budget;
+  uint32_t next_stream = 0;
+  bool in_group = false;
+  uint64_t block0 = 0;
+  std::vector<uint32_t> order; /* the current group, longest stream first */
+
+  TilePlanner(const uint64_t *blocks_per_stream, uint32_t num_streams, uint64_t bytes_per_block, uint64_t tile_budget)
+      : blocks(blocks_per_stream), n(num_streams), block_cost(bytes_per_block ? bytes_per_block : 1), budget(tile_budget) {}
+
+  bool next(TileStep *t)
   {
-    if (pos >= n) return false;
-    uint64_t sum = 0;
-    *first = pos;
-    do sum += cost(pos++); while (pos < n && sum + cost(pos) <= budget);
-    *last = pos;
-    return true;
+    for (;;) {
+      bool first = false;
+      if (!in_group) {
+        if (next_stream >= n) return false;
+        order.clear();
+        uint64_t cost = 0;
+        do {
+          order.push_back(next_stream);
+          if (blocks[next_stream]) cost += block_cost;
+          next_stream++;
+        } while (next_stream < n && cost < budget);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return blocks[x] > blocks[y]; });
+        block0 = 0;
+        in_group = true;
+        first = true;
+      }
+      /* streams with more than block0 blocks: a prefix of the order */
+      uint32_t lo = 0, hi = (uint32_t)order.size();
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (blocks[order[mid]] > block0) lo = mid + 1; else hi = mid;
+      }
+      if (lo == 0) { /* a group of empty streams */
+        in_group = false;
+        continue;
+      }
+      const uint64_t longest = blocks[order[0]];
+      uint64_t per_tile = budget / ((uint64_t)lo * block_cost);
+      if (per_tile == 0) per_tile = 1;
+      t->alive = lo;
+      t->block0 = block0;
+      t->block1 = longest - block0 <= per_tile ? longest : block0 + per_tile;
+      t->group_first = first;
+      t->group_last = t->block1 >= longest;
+      block0 = t->block1;
+      if (t->group_last) in_group = false;
+      return true;
+    }
   }
 };
 
-/* one chunk in flight on buffer pair b */
-struct Flight {
-  uint32_t first = 0, last = 0;
-  bool active = false;
+/* what the host still has to do with a tile once its copies are back */
+struct Delivery {
+  uint32_t stream;
+  uint64_t src;   /* offset in the pair's output block (encode: bytes, decode: int16 elements) */
+  uint64_t dst;   /* encode: byte offset in the caller's image; decode: first frame */
+  uint64_t count; /* encode: bytes; decode: frames */
 };
 
+struct Flight {
+  bool active = false;
+  uint64_t sequence = 0;
+  std::vector<Delivery> items;
+  std::vector<uint64_t> cost;        /* running bytes over items: [items + 1] */
+  std::vector<uint32_t> state_order; /* encode, last tile of a group: the group's order, else empty */
+  uint64_t state_src = 0;
+};
+
+bool batch_is_cut(const AADHipContext *ctx, uint64_t total_bytes) { return ctx->tile_bytes > 0 || total_bytes > kCutAbove; }
+
+uint64_t tile_budget(const AADHipContext *ctx, uint64_t total_bytes)
+{
+  if (ctx->tile_bytes > 0) return (uint64_t)ctx->tile_bytes; /* forced: tests, tuning */
+  return total_bytes > kCutAbove ? kChunkBudget : ~0ull >> 8;
+}
+
+bool state_reserve(AADHipContext *ctx, size_t records)
+{
+  if (records <= ctx->state_capacity) return true;
+  if (ctx->d_state) (void)hipFree(ctx->d_state); /* waits for the device: nothing is still reading it */
+  ctx->d_state = nullptr;
+  ctx->state_capacity = 0;
+  const size_t want = records + records / 4 + 64;
+  if (!hip_ok(ctx, hipMalloc(&ctx->d_state, sizeof(AADHipLaneState) * want), "hipMalloc lane states")) return false;
+  ctx->state_capacity = want;
+  return true;
+}
+
 /*
- * Encode num_streams host streams.  fill(i, dst) writes stream i's interleaved int16 frames,
- * drain(i, src, size) receives its .aad image.  `state` as in AADHip_EncodeBatch.
+ * Encode num_streams host streams.  fill(i, frame0, frames, dst) writes that range of stream i's
+ * interleaved int16 frames, drain(i, offset, src, size) receives bytes [offset, offset + size) of
+ * its .aad image.  `state` as in AADHip_EncodeBatch.
  */
 template <class Fill, class Drain>
 AADApiResult encode_host(AADHipContext *ctx, const struct AADEncodeParameter *parameter, uint32_t num_streams,
                          const uint32_t *num_samples, const uint64_t *data_capacity, uint64_t *output_size,
                          struct AADHipLaneState *state, Fill fill, Drain drain)
 {
-  const uint32_t ch = parameter->num_channels;
-  std::vector<uint64_t> sizes(num_streams);
+  AADHeaderInfo h;
+  if (AADFormat_ParameterToHeader(parameter, 1, AAD_HIP_MAX_NUM_CHANNELS, &h) != AAD_APIRESULT_OK ||
+      !AADFormat_HeaderFieldsValid(&h, AAD_HIP_MAX_NUM_CHANNELS))
+    return AAD_APIRESULT_INVALID_FORMAT;
+  const uint32_t ch = h.num_channels, spb = h.num_samples_per_block;
+  std::vector<uint64_t> sizes(num_streams), blocks(num_streams);
   uint64_t total = 0;
   for (uint32_t i = 0; i < num_streams; i++) {
-    sizes[i] = AADHip_CalculateEncodedSize(parameter, num_samples[i]);
-    if (sizes[i] == 0) return AAD_APIRESULT_INVALID_FORMAT;
+    if (num_samples[i] == 0) return AAD_APIRESULT_INVALID_FORMAT; /* src/aad_encoder.c:157-159 */
+    h.num_samples = num_samples[i];
+    sizes[i] = AADFormat_EncodedSize(&h);
     if (data_capacity[i] < sizes[i]) return AAD_APIRESULT_INSUFFICIENT_BUFFER;
+    blocks[i] = ((uint64_t)num_samples[i] + spb - 1) / spb;
     total += (uint64_t)num_samples[i] * ch * sizeof(int16_t) + sizes[i];
   }
   DeviceGuard guard(ctx);
   if (!guard.ok || !ensure_events(ctx)) return AAD_APIRESULT_NG;
 
-  auto cost = [&](uint32_t i) { return (uint64_t)num_samples[i] * ch * sizeof(int16_t) + sizes[i]; };
-  ChunkCutter cutter(total, num_streams);
+  TilePlanner planner(blocks.data(), num_streams, (uint64_t)spb * ch * sizeof(int16_t) + h.block_size, tile_budget(ctx, total));
+  if (batch_is_cut(ctx, total) && !ensure_pipeline(ctx)) return AAD_APIRESULT_NG;
+  const Route route = route_for(ctx, batch_is_cut(ctx, total));
   Flight flight[2];
   std::vector<AADHipStreamDesc> table;
+  std::vector<uint64_t> fill_cost;
+  uint64_t sequence = 0;
 
-  /* wait for the chunk on pair b and hand its images (and states) to the caller */
+  /* wait for the tile on pair b and hand its image bytes (and states) to the caller */
   auto finish = [&](int b) -> bool {
     Flight &f = flight[b];
     if (!f.active) return true;
     f.active = false;
     if (!hip_ok(ctx, hipEventSynchronize(ctx->chunk_done[b]), "hipEventSynchronize")) return false;
     const uint8_t *out = static_cast<const uint8_t *>(ctx->out[b].host);
-    uint64_t off = 0;
-    for (uint32_t i = f.first; i < f.last; i++) {
-      drain(i, out + off, sizes[i]);
-      off += round_up(sizes[i], 16);
+    staged_ranges(ctx, (uint32_t)f.items.size(), f.cost, [&](uint32_t lo, uint32_t hi) {
+      for (uint32_t k = lo; k < hi; k++) {
+        const Delivery &d = f.items[k];
+        drain(d.stream, d.dst, out + d.src, d.count);
+        if (d.dst == 0 && d.count < sizes[d.stream]) { /* first tile of a longer stream: the header carries the whole count */
+          const uint32_t all = num_samples[d.stream];
+          const uint8_t be[4] = {(uint8_t)(all >> 24), (uint8_t)(all >> 16), (uint8_t)(all >> 8), (uint8_t)all};
+          drain(d.stream, 14, be, 4);
+        }
+      }
+    });
+    if (state) {
+      const AADHipLaneState *records = reinterpret_cast<const AADHipLaneState *>(out + f.state_src);
+      for (size_t slot = 0; slot < f.state_order.size(); slot++)
+        memcpy(state + (size_t)f.state_order[slot] * ch, records + slot * ch, sizeof(AADHipLaneState) * ch);
     }
-    if (state) memcpy(state + (size_t)f.first * ch, out + off, sizeof(AADHipLaneState) * (size_t)(f.last - f.first) * ch);
     return true;
   };
 
   AADApiResult rc = AAD_APIRESULT_OK;
-  uint32_t first, last;
-  for (int k = 0; rc == AAD_APIRESULT_OK && cutter.next(cost, &first, &last); k++) {
-    const int b = k & 1;
+  TileStep step;
+  while (rc == AAD_APIRESULT_OK && planner.next(&step)) {
+    const int b = (int)(sequence & 1);
     if (!finish(b)) { rc = AAD_APIRESULT_NG; break; }
-    const uint32_t n = last - first;
-    /* input block: table | state | pcm ; output block: images | state */
+    const uint32_t n = step.alive;
+    const std::vector<uint32_t> &order = planner.order;
+    const uint32_t group_size = (uint32_t)order.size();
+    Flight &f = flight[b];
+    /* input block: table | state | pcm ; output block: image slices | state */
     table.resize(n);
+    f.items.resize(n);
+    f.cost.resize((size_t)n + 1);
+    fill_cost.resize((size_t)n + 1);
     uint64_t pcm_elems = 0, data_bytes = 0;
-    for (uint32_t i = 0; i < n; i++) {
-      table[i].pcm_offset = pcm_elems;
-      table[i].data_offset = data_bytes;
-      table[i].data_size = sizes[first + i];
-      table[i].num_samples = num_samples[first + i];
-      table[i].reserved = 0;
-      pcm_elems += round_up((uint64_t)num_samples[first + i] * ch, 8);
-      data_bytes += round_up(sizes[first + i], 16);
+    /* the trial search looks one block back in the input: later tiles bring that block along */
+    const uint32_t lead = parameter->num_encode_trials > 0 && step.block0 > 0 ? spb : 0;
+    for (uint32_t k = 0; k < n; k++) {
+      const uint32_t i = order[k];
+      const uint64_t frame0 = step.block0 * spb;
+      const uint64_t frame1 = step.block1 * spb < num_samples[i] ? step.block1 * spb : num_samples[i];
+      /* file header + this tile's blocks: up to the stream's end, or whole blocks */
+      const uint64_t slice = AAD_HEADER_SIZE + (step.block1 >= blocks[i] ? sizes[i] - AAD_HEADER_SIZE - step.block0 * h.block_size
+                                                                         : (step.block1 - step.block0) * h.block_size);
+      h.num_samples = (uint32_t)(frame1 - frame0) + lead;
+      table[k].pcm_offset = pcm_elems;
+      table[k].data_offset = data_bytes;
+      table[k].data_size = slice;
+      table[k].num_samples = h.num_samples;
+      table[k].reserved = 0;
+      /* the first tile delivers the file header too; later ones only their blocks */
+      const uint64_t skip = step.block0 ? AAD_HEADER_SIZE : 0;
+      f.items[k] = {i, data_bytes + skip, step.block0 ? AAD_HEADER_SIZE + step.block0 * h.block_size : 0, slice - skip};
+      f.cost[k] = data_bytes;
+      fill_cost[k] = pcm_elems * sizeof(int16_t);
+      pcm_elems += round_up((uint64_t)h.num_samples * ch, 8);
+      data_bytes += round_up(slice, 16);
     }
+    f.cost[n] = data_bytes;
+    fill_cost[n] = pcm_elems * sizeof(int16_t);
     aad::EncodeArgs a;
-    rc = encode_plan_init(parameter, n, table.data(), &a);
+    rc = encode_plan_init(parameter, n, table.data(), &a, lead, true);
     if (rc != AAD_APIRESULT_OK) break;
+    /* states live on the device while a group has tiles to go; the caller's come in with the first
+     * tile and leave with the last */
+    const bool lone = step.group_first && step.group_last; /* the group's only tile: states travel inside its blocks */
+    const bool carry = !lone;
+    const bool state_in = state != nullptr && step.group_first, state_back = state != nullptr && step.group_last;
     const size_t table_bytes = round_up(sizeof(AADHipStreamDesc) * (size_t)n, 64);
-    const size_t state_bytes = state ? sizeof(AADHipLaneState) * (size_t)n * ch : 0;
-    const size_t pcm_off = table_bytes + round_up(state_bytes, 64);
+    const size_t state_in_bytes = state_in ? sizeof(AADHipLaneState) * (size_t)n * ch : 0;
+    const size_t state_back_bytes = state_back ? sizeof(AADHipLaneState) * (size_t)group_size * ch : 0;
+    const size_t pcm_off = table_bytes + round_up(state_in_bytes, 64);
     const size_t in_bytes = pcm_off + pcm_elems * sizeof(int16_t);
-    const size_t out_bytes = data_bytes + state_bytes;
+    const size_t out_bytes = data_bytes + state_back_bytes;
     rc = AAD_APIRESULT_NG;
     if (!staging_reserve(ctx, ctx->in[b], in_bytes + 64) || !staging_reserve(ctx, ctx->out[b], out_bytes + 64)) break;
+    if (carry && !state_reserve(ctx, (size_t)group_size * ch)) break;
     uint8_t *hin = static_cast<uint8_t *>(ctx->in[b].host), *din = static_cast<uint8_t *>(ctx->in[b].dev);
     uint8_t *dout = static_cast<uint8_t *>(ctx->out[b].dev);
     memcpy(hin, table.data(), sizeof(AADHipStreamDesc) * (size_t)n);
-    if (state) memcpy(hin + table_bytes, state + (size_t)first * ch, state_bytes);
-    for (uint32_t i = 0; i < n; i++) fill(first + i, reinterpret_cast<int16_t *>(hin + pcm_off) + table[i].pcm_offset);
-    if (!hip_ok(ctx, hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D block")) break;
+    if (state_in) /* every stream of a group is alive in its first tile: n == group_size */
+      for (uint32_t k = 0; k < n; k++)
+        memcpy(hin + table_bytes + sizeof(AADHipLaneState) * (size_t)k * ch, state + (size_t)order[k] * ch, sizeof(AADHipLaneState) * ch);
+    staged_ranges(ctx, n, fill_cost, [&](uint32_t lo, uint32_t hi) {
+      for (uint32_t k = lo; k < hi; k++)
+        fill(order[k], (uint32_t)(step.block0 * spb - lead), table[k].num_samples, reinterpret_cast<int16_t *>(hin + pcm_off) + table[k].pcm_offset);
+    });
+    if (!hip_ok(ctx, hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, route.up), "H2D block")) break;
+    if (!hop(ctx, ctx->uploaded[b], route.up, route.run)) break;
+    aad::LaneStateRecord *d_state = static_cast<aad::LaneStateRecord *>(ctx->d_state);
     a.streams = reinterpret_cast<const aad::StreamDesc *>(din);
     a.pcm = reinterpret_cast<const int16_t *>(din + pcm_off);
     a.data = dout;
-    a.state = state ? reinterpret_cast<const aad::LaneStateRecord *>(din + table_bytes) : nullptr;
-    a.state_out = state ? reinterpret_cast<aad::LaneStateRecord *>(dout + data_bytes) : nullptr;
+    a.state = state_in ? reinterpret_cast<const aad::LaneStateRecord *>(din + table_bytes) : (step.group_first ? nullptr : d_state);
+    a.state_out = carry ? d_state : (state_back ? reinterpret_cast<aad::LaneStateRecord *>(dout + data_bytes) : nullptr);
     if (run_encode(ctx, a) != AAD_APIRESULT_OK) break;
-    if (!hip_ok(ctx, hipMemcpyAsync(ctx->out[b].host, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H block")) break;
-    if (!hip_ok(ctx, hipEventRecord(ctx->chunk_done[b], ctx->stream), "hipEventRecord")) break;
-    flight[b].first = first;
-    flight[b].last = last;
-    flight[b].active = true;
+    f.state_order.clear();
+    if (state_back) {
+      /* from the device-side records on the compute stream: the next group's first launch overwrites them */
+      if (carry && !hip_ok(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->out[b].host) + data_bytes, d_state, state_back_bytes, hipMemcpyDeviceToHost, route.run), "D2H lane states")) break;
+      f.state_order = order;
+      f.state_src = data_bytes;
+    }
+    if (!hop(ctx, ctx->computed[b], route.run, route.down)) break;
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->out[b].host, dout, lone ? out_bytes : data_bytes, hipMemcpyDeviceToHost, route.down), "D2H block")) break;
+    if (!hip_ok(ctx, hipEventRecord(ctx->chunk_done[b], route.down), "hipEventRecord")) break;
+    f.sequence = sequence++;
+    f.active = true;
     rc = AAD_APIRESULT_OK;
   }
   /* drain what is still in flight, oldest first (also on failure: the buffers must be idle on return) */
-  const int older = flight[0].active && flight[1].active && flight[1].first < flight[0].first ? 1 : 0;
+  const int older = flight[0].active && flight[1].active && flight[1].sequence < flight[0].sequence ? 1 : 0;
   if (!finish(older) && rc == AAD_APIRESULT_OK) rc = AAD_APIRESULT_NG;
   if (!finish(older ^ 1) && rc == AAD_APIRESULT_OK) rc = AAD_APIRESULT_NG;
+  if (rc != AAD_APIRESULT_OK) settle(route); /* a tile that failed half way may have left copies queued */
   if (rc == AAD_APIRESULT_OK && output_size) memcpy(output_size, sizes.data(), sizeof(uint64_t) * num_streams);
   return rc;
 }
 
 /*
- * Decode num_streams host images of one format.  fill(i, dst) writes stream i's bytes
- * (data_size[i] of them), drain(i, src, frames) receives its interleaved int16 frames.
+ * Decode num_streams host images of one format.  fill(i, offset, size, dst) writes bytes
+ * [offset, offset + size) of stream i's image, drain(i, frame0, src, frames) receives that range
+ * of its interleaved int16 frames.  Tiles carry bare blocks (the file header stays on the host).
  */
 template <class Fill, class Drain>
 AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format, int32_t has_file_header,
@@ -847,23 +1211,32 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
                          uint32_t *decoded_frames, Fill fill, Drain drain)
 {
   const uint32_t ch = format->num_channels, head = has_file_header ? AAD_HEADER_SIZE : 0;
-  if (ch == 0 || format->block_size == 0) return AAD_APIRESULT_INVALID_FORMAT;
+  const uint32_t spb = format->num_samples_per_block, bs = format->block_size;
+  if (ch == 0 || bs == 0 || spb == 0) return AAD_APIRESULT_INVALID_FORMAT;
+  std::vector<AADHipStreamDesc> table(num_streams);
+  std::vector<uint64_t> prefix((size_t)num_streams + 1), blocks(num_streams), fill_cost, tile_blocks;
   uint64_t total = 0;
-  for (uint32_t i = 0; i < num_streams; i++) total += data_size[i] + (uint64_t)num_samples[i] * ch * sizeof(int16_t);
+  for (uint32_t i = 0; i < num_streams; i++) {
+    table[i] = {0, 0, data_size[i], num_samples[i], 0};
+    total += data_size[i] + (uint64_t)num_samples[i] * ch * sizeof(int16_t);
+  }
+  {
+    /* the whole batch is validated before the first tile runs: a bad stream fails the call with
+     * nothing decoded, as it did when a batch was one launch */
+    aad::DecodeArgs whole;
+    const AADApiResult ok = decode_plan_init(format, has_file_header, num_streams, table.data(), prefix.data(), &whole);
+    if (ok != AAD_APIRESULT_OK) return ok;
+    for (uint32_t i = 0; i < num_streams; i++) blocks[i] = prefix[i + 1] - prefix[i];
+  }
   DeviceGuard guard(ctx);
   if (!guard.ok || !ensure_events(ctx)) return AAD_APIRESULT_NG;
+  if (decoded_frames) memset(decoded_frames, 0, sizeof(uint32_t) * num_streams);
 
-  auto cost = [&](uint32_t i) { return data_size[i] + (uint64_t)num_samples[i] * ch * sizeof(int16_t); };
-  /* frames the reference's block walk produces: it stops when the bytes run out (src/aad_decoder.c:514) */
-  auto frames_of = [&](uint32_t i) -> uint32_t {
-    const uint64_t payload = data_size[i] > head ? data_size[i] - head : 0;
-    const uint64_t frames = (payload + format->block_size - 1) / format->block_size * format->num_samples_per_block;
-    return frames < num_samples[i] ? (uint32_t)frames : num_samples[i];
-  };
-  ChunkCutter cutter(total, num_streams);
+  TilePlanner planner(blocks.data(), num_streams, (uint64_t)spb * ch * sizeof(int16_t) + bs, tile_budget(ctx, total));
+  if (batch_is_cut(ctx, total) && !ensure_pipeline(ctx)) return AAD_APIRESULT_NG;
+  const Route route = route_for(ctx, batch_is_cut(ctx, total));
   Flight flight[2];
-  std::vector<AADHipStreamDesc> table;
-  std::vector<uint64_t> prefix;
+  uint64_t sequence = 0;
 
   auto finish = [&](int b) -> bool {
     Flight &f = flight[b];
@@ -871,36 +1244,54 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
     f.active = false;
     if (!hip_ok(ctx, hipEventSynchronize(ctx->chunk_done[b]), "hipEventSynchronize")) return false;
     const int16_t *out = static_cast<const int16_t *>(ctx->out[b].host);
-    uint64_t off = 0;
-    for (uint32_t i = f.first; i < f.last; i++) {
-      const uint32_t got = frames_of(i);
-      if (got) drain(i, out + off, got);
-      if (decoded_frames) decoded_frames[i] = got;
-      off += round_up((uint64_t)num_samples[i] * ch, 8);
-    }
+    staged_ranges(ctx, (uint32_t)f.items.size(), f.cost, [&](uint32_t lo, uint32_t hi) {
+      for (uint32_t k = lo; k < hi; k++) {
+        const Delivery &d = f.items[k];
+        if (d.count) drain(d.stream, (uint32_t)d.dst, out + d.src, (uint32_t)d.count);
+        if (decoded_frames) decoded_frames[d.stream] += (uint32_t)d.count; /* one item per stream and tile */
+      }
+    });
     return true;
   };
 
   AADApiResult rc = AAD_APIRESULT_OK;
-  uint32_t first, last;
-  for (int k = 0; rc == AAD_APIRESULT_OK && cutter.next(cost, &first, &last); k++) {
-    const int b = k & 1;
+  TileStep step;
+  while (rc == AAD_APIRESULT_OK && planner.next(&step)) {
+    const int b = (int)(sequence & 1);
     if (!finish(b)) { rc = AAD_APIRESULT_NG; break; }
-    const uint32_t n = last - first;
+    const uint32_t n = step.alive;
+    const std::vector<uint32_t> &order = planner.order;
+    Flight &f = flight[b];
     table.resize(n);
     prefix.resize((size_t)n + 1);
+    tile_blocks.resize(n);
+    f.items.resize(n);
+    f.cost.resize((size_t)n + 1);
+    fill_cost.resize((size_t)n + 1);
     uint64_t pcm_elems = 0, data_bytes = 0;
-    for (uint32_t i = 0; i < n; i++) {
-      table[i].pcm_offset = pcm_elems;
-      table[i].data_offset = data_bytes;
-      table[i].data_size = data_size[first + i];
-      table[i].num_samples = num_samples[first + i];
-      table[i].reserved = 0;
-      pcm_elems += round_up((uint64_t)num_samples[first + i] * ch, 8);
-      data_bytes += round_up(data_size[first + i], 16);
+    for (uint32_t k = 0; k < n; k++) {
+      const uint32_t i = order[k];
+      const uint64_t payload = data_size[i] - head; /* alive: it has a block, so more than `head` bytes */
+      const uint64_t byte0 = step.block0 * bs, byte1 = step.block1 * bs < payload ? step.block1 * bs : payload;
+      const uint64_t frame0 = step.block0 * spb, frame1 = step.block1 * spb < num_samples[i] ? step.block1 * spb : num_samples[i];
+      /* frames the reference's block walk produces: it stops when the bytes run out (src/aad_decoder.c:514) */
+      tile_blocks[k] = (step.block1 < blocks[i] ? step.block1 : blocks[i]) - step.block0;
+      const uint64_t by_bytes = tile_blocks[k] * spb;
+      table[k].pcm_offset = pcm_elems;
+      table[k].data_offset = data_bytes;
+      table[k].data_size = byte1 - byte0;
+      table[k].num_samples = (uint32_t)(frame1 - frame0);
+      table[k].reserved = 0;
+      f.items[k] = {i, pcm_elems, frame0, by_bytes < frame1 - frame0 ? by_bytes : frame1 - frame0};
+      f.cost[k] = pcm_elems * sizeof(int16_t);
+      fill_cost[k] = data_bytes;
+      pcm_elems += round_up((frame1 - frame0) * ch, 8);
+      data_bytes += round_up(byte1 - byte0, 16);
     }
+    f.cost[n] = pcm_elems * sizeof(int16_t);
+    fill_cost[n] = data_bytes;
     aad::DecodeArgs a;
-    rc = decode_plan_init(format, has_file_header, n, table.data(), prefix.data(), &a);
+    rc = decode_plan_init(format, 0, n, table.data(), prefix.data(), &a, tile_blocks.data());
     if (rc != AAD_APIRESULT_OK) break;
     const size_t table_bytes = round_up(sizeof(AADHipStreamDesc) * (size_t)n, 64);
     const size_t prefix_bytes = round_up(sizeof(uint64_t) * ((size_t)n + 1), 64);
@@ -911,24 +1302,29 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
     uint8_t *hin = static_cast<uint8_t *>(ctx->in[b].host), *din = static_cast<uint8_t *>(ctx->in[b].dev);
     memcpy(hin, table.data(), sizeof(AADHipStreamDesc) * (size_t)n);
     memcpy(hin + table_bytes, prefix.data(), sizeof(uint64_t) * ((size_t)n + 1));
-    for (uint32_t i = 0; i < n; i++) fill(first + i, hin + data_off + table[i].data_offset);
-    if (!hip_ok(ctx, hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D block")) break;
+    staged_ranges(ctx, n, fill_cost, [&](uint32_t lo, uint32_t hi) {
+      for (uint32_t k = lo; k < hi; k++)
+        fill(order[k], head + step.block0 * bs, table[k].data_size, hin + data_off + table[k].data_offset);
+    });
+    if (!hip_ok(ctx, hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, route.up), "H2D block")) break;
+    if (!hop(ctx, ctx->uploaded[b], route.up, route.run)) break;
     a.streams = reinterpret_cast<const aad::StreamDesc *>(din);
     a.block_prefix = reinterpret_cast<const uint64_t *>(din + table_bytes);
     a.data = din + data_off;
     a.pcm = static_cast<int16_t *>(ctx->out[b].dev);
     if ((reinterpret_cast<uintptr_t>(a.pcm) & 63u) != 0) a.stream_stores = 0;
     if (run_decode(ctx, a) != AAD_APIRESULT_OK) break;
-    if (out_bytes && !hip_ok(ctx, hipMemcpyAsync(ctx->out[b].host, ctx->out[b].dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H block")) break;
-    if (!hip_ok(ctx, hipEventRecord(ctx->chunk_done[b], ctx->stream), "hipEventRecord")) break;
-    flight[b].first = first;
-    flight[b].last = last;
-    flight[b].active = true;
+    if (!hop(ctx, ctx->computed[b], route.run, route.down)) break;
+    if (out_bytes && !hip_ok(ctx, hipMemcpyAsync(ctx->out[b].host, ctx->out[b].dev, out_bytes, hipMemcpyDeviceToHost, route.down), "D2H block")) break;
+    if (!hip_ok(ctx, hipEventRecord(ctx->chunk_done[b], route.down), "hipEventRecord")) break;
+    f.sequence = sequence++;
+    f.active = true;
     rc = AAD_APIRESULT_OK;
   }
-  const int older = flight[0].active && flight[1].active && flight[1].first < flight[0].first ? 1 : 0;
+  const int older = flight[0].active && flight[1].active && flight[1].sequence < flight[0].sequence ? 1 : 0;
   if (!finish(older) && rc == AAD_APIRESULT_OK) rc = AAD_APIRESULT_NG;
   if (!finish(older ^ 1) && rc == AAD_APIRESULT_OK) rc = AAD_APIRESULT_NG;
+  if (rc != AAD_APIRESULT_OK) settle(route);
   return rc;
 }
 
@@ -949,8 +1345,10 @@ AADApiResult AADHip_EncodeBatch(struct AADHipContext *ctx, const struct AADEncod
     if (pcm[i] == nullptr || data[i] == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
   const size_t frame_bytes = sizeof(int16_t) * parameter->num_channels;
   return encode_host(ctx, parameter, num_streams, num_samples, data_capacity, output_size, state,
-                     [&](uint32_t i, int16_t *dst) { memcpy(dst, pcm[i], (size_t)num_samples[i] * frame_bytes); },
-                     [&](uint32_t i, const uint8_t *src, uint64_t size) { memcpy(data[i], src, size); });
+                     [&](uint32_t i, uint32_t frame0, uint32_t frames, int16_t *dst) {
+                       memcpy(dst, pcm[i] + (size_t)frame0 * parameter->num_channels, (size_t)frames * frame_bytes);
+                     },
+                     [&](uint32_t i, uint64_t offset, const uint8_t *src, uint64_t size) { memcpy(data[i] + offset, src, size); });
 }
 
 /* AADEncoder_EncodeWhole's data path (src/aad_encoder.c:814-891): planar int32 rows in, one image
@@ -963,17 +1361,17 @@ AADApiResult AADHipInternal_EncodePlanar32(struct AADHipContext *ctx, const stru
 {
   const uint32_t ch = parameter->num_channels;
   return encode_host(ctx, parameter, 1, &num_samples, &data_capacity, output_size, state,
-                     [&](uint32_t, int16_t *dst) {
+                     [&](uint32_t, uint32_t frame0, uint32_t frames, int16_t *dst) {
                        for (uint32_t c = 0; c < ch; c++) {
-                         const int32_t *x = input[c];
+                         const int32_t *x = input[c] + frame0;
                          int16_t *d = dst + c;
-                         for (uint32_t s = 0; s < num_samples; s++, d += ch) {
+                         for (uint32_t s = 0; s < frames; s++, d += ch) {
                            const int32_t v = x[s];
                            *d = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
                          }
                        }
                      },
-                     [&](uint32_t, const uint8_t *src, uint64_t size) { memcpy(data, src, size); });
+                     [&](uint32_t, uint64_t offset, const uint8_t *src, uint64_t size) { memcpy(data + offset, src, size); });
 }
 
 /* shared by AADHip_DecodeBatch (file images) and the legacy AADDecoder_DecodeBlock (bare block) */
@@ -984,8 +1382,10 @@ AADApiResult AADHipInternal_DecodeHost(struct AADHipContext *ctx, const struct A
 {
   const size_t frame_bytes = sizeof(int16_t) * format->num_channels;
   return decode_host(ctx, format, has_file_header, num_streams, data_size, num_samples, decoded_frames,
-                     [&](uint32_t i, uint8_t *dst) { memcpy(dst, data[i], data_size[i]); },
-                     [&](uint32_t i, const int16_t *src, uint32_t frames) { memcpy(pcm[i], src, (size_t)frames * frame_bytes); });
+                     [&](uint32_t i, uint64_t offset, uint64_t size, uint8_t *dst) { memcpy(dst, data[i] + offset, size); },
+                     [&](uint32_t i, uint32_t frame0, const int16_t *src, uint32_t frames) {
+                       memcpy(pcm[i] + (size_t)frame0 * format->num_channels, src, (size_t)frames * frame_bytes);
+                     });
 }
 
 /* AADDecoder_DecodeWhole / DecodeBlock's data path: one image (or bare block) in, planar int32
@@ -996,10 +1396,10 @@ AADApiResult AADHipInternal_DecodePlanar32(struct AADHipContext *ctx, const stru
 {
   const uint32_t ch = format->num_channels;
   return decode_host(ctx, format, has_file_header, 1, &data_size, &want_frames, decoded_frames,
-                     [&](uint32_t, uint8_t *dst) { memcpy(dst, data, data_size); },
-                     [&](uint32_t, const int16_t *src, uint32_t frames) {
+                     [&](uint32_t, uint64_t offset, uint64_t size, uint8_t *dst) { memcpy(dst, data + offset, size); },
+                     [&](uint32_t, uint32_t frame0, const int16_t *src, uint32_t frames) {
                        for (uint32_t c = 0; c < ch; c++) {
-                         int32_t *y = buffer[c];
+                         int32_t *y = buffer[c] + frame0;
                          const int16_t *s = src + c;
                          for (uint32_t k = 0; k < frames; k++, s += ch) y[k] = *s;
                        }

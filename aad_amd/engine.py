@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from .capi import (AADApiResult, AADHeaderInfo, ApiError, ERROR_STATS_DTYPE, LANE_MAPPINGS, LANE_STATE_DTYPE,
-                   OPTION_LANE_MAPPING, OPTION_TRIAL_LANES, RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL,
+                   OPTION_LANE_MAPPING, OPTION_STAGING_THREADS, OPTION_TILE_KBYTES, OPTION_TRIAL_LANES, RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL,
                    STREAM_DESC_DTYPE, TRIAL_LANES, load_library, make_parameter)
 
 
@@ -82,6 +82,17 @@ class Engine:
         if trial_lanes is not None:
             _check("AADHip_ContextSetOption",
                    self.lib.AADHip_ContextSetOption(self._ctx, OPTION_TRIAL_LANES, TRIAL_LANES[trial_lanes]))
+
+    def set_staging_threads(self, threads=0):
+        """Threads that copy between caller buffers and the pinned staging blocks in the host-memory
+        entry points: 0 = by core count, 1 = the calling thread alone, up to 8."""
+        _check("AADHip_ContextSetOption",
+               self.lib.AADHip_ContextSetOption(self._ctx, OPTION_STAGING_THREADS, int(threads)))
+
+    def set_tile_kbytes(self, kbytes=0):
+        """Tile budget (KiB) of the host-memory entry points; 0 = built in.  Results do not depend on it."""
+        _check("AADHip_ContextSetOption",
+               self.lib.AADHip_ContextSetOption(self._ctx, OPTION_TILE_KBYTES, int(kbytes)))
 
     def synchronize(self):
         _check("AADHip_ContextSynchronize", self.lib.AADHip_ContextSynchronize(self._ctx))

@@ -69,12 +69,22 @@ AADApiResult AADHip_ContextSynchronize(struct AADHipContext *context);
 const char *AADHip_ContextLastError(const struct AADHipContext *context);
 
 /* Launch options of a context.  Defaults: the environment variables AAD_HIP_MAPPING
- * (auto | dense | quad | quad-fused) and AAD_HIP_TRIAL_LANES (dual | single), read ONCE when the
- * context is created; the library never calls getenv afterwards.  An option holds for every later
+ * (auto | dense | quad | quad-fused), AAD_HIP_TRIAL_LANES (dual | single),
+ * AAD_HIP_STAGING_THREADS (1..8) and AAD_HIP_TILE_KBYTES, read ONCE when the context is created; the library never calls getenv afterwards.  An option holds for every later
  * ...Run / ...Batch call of the context; set it from the thread that owns the context. */
 enum AADHipOption {
   AAD_HIP_OPTION_LANE_MAPPING = 0, /* enum AADHipLaneMapping */
-  AAD_HIP_OPTION_TRIAL_LANES = 1   /* enum AADHipTrialLanes */
+  AAD_HIP_OPTION_TRIAL_LANES = 1,  /* enum AADHipTrialLanes */
+  /* Threads that copy between the caller's buffers and the pinned staging blocks in the host-memory
+   * entry points (...Batch, EncodeWhole/DecodeWhole), the caller's own included: 0 = by core count
+   * (4 from eight cores, 2 from four), 1 = the caller alone (no helper thread is ever started),
+   * up to 8.  Helpers start at the first chunk of a megabyte or more and end in ContextDestroy. */
+  AAD_HIP_OPTION_STAGING_THREADS = 2,
+  /* Budget, in KiB, of one tile of the host-memory entry points (input + output bytes that travel
+   * together; see DESIGN.md "host-memory path"): 0 = built in (batches up to 16 MiB go as one tile,
+   * larger ones in 8 MiB tiles).  A tile never holds less than one block of one stream.  Default from
+   * AAD_HIP_TILE_KBYTES.  Results do not depend on it. */
+  AAD_HIP_OPTION_TILE_KBYTES = 3
 };
 enum AADHipLaneMapping {
   AAD_HIP_LANE_MAPPING_AUTO = 0,      /* by batch size (the default) */

@@ -189,6 +189,91 @@ def test_ragged_batch_vs_oracle(engine, bits, channels, mapping):
             assert np.array_equal(d, ob.decode(img)[0]), (i, lens[i])
 
 
+def test_staging_threads_do_not_change_bytes(engine):
+    """Host-memory batches above a megabyte are staged by helper threads (AAD_HIP_OPTION_STAGING_THREADS);
+    a ragged 12 MB batch - several chunks' worth at 8 threads' ranges, one 1.2 MB stream among short
+    ones - must come back identical whatever the thread count, and equal to the oracle on a sample."""
+    rng = np.random.default_rng(77)
+    lens = [int(v) for v in rng.integers(1, 9000, 700)]
+    lens[13] = 300000
+    lens[699] = 1
+    kinds = ["music", "noise", "nyquist"]
+    pcms = [synth_pcm(1, n, 2, seed=5000 + i, kind=kinds[i % 3])[0] for i, n in enumerate(lens)]
+    param = make_parameter(2, 4, 1024, 48000, False, 0)
+    try:
+        engine.set_staging_threads(1)
+        want_images = engine.encode_host(pcms, param)
+        want_pcm = engine.decode_host(want_images)
+        for threads in (3, 8, 0):
+            engine.set_staging_threads(threads)
+            images = engine.encode_host(pcms, param)
+            assert images == want_images, threads
+            decoded = engine.decode_host(images)
+            assert all(np.array_equal(a, b) for a, b in zip(decoded, want_pcm)), threads
+    finally:
+        engine.set_staging_threads(0)
+    for i in (0, 13, 350, 698, 699):
+        assert want_images[i] == ob.encode(pcms[i], 4, 1024, 48000, False, 0), i
+        assert np.array_equal(want_pcm[i], ob.decode(want_images[i])[0]), i
+    with pytest.raises(Exception):
+        engine.set_staging_threads(9)
+
+
+@pytest.mark.parametrize("kbytes", [1, 24, 200])
+@pytest.mark.parametrize("bits,channels,ms,trials,mbs", [(4, 2, False, 0, 256), (4, 2, True, 1, 128), (3, 1, False, 0, 64),
+                                                         (2, 3, False, 2, 96), (4, 8, False, 0, 256)])
+def test_tiled_host_path_is_tile_size_independent(engine, kbytes, bits, channels, ms, trials, mbs):
+    """The host-memory path cuts a batch into groups of streams and tiles of blocks, the encoder's
+    predictor state staying on the device between a group's tiles (AAD_HIP_OPTION_TILE_KBYTES forces
+    the cut on small data).  Ragged lengths - one-sample streams next to 100-block ones, streams that
+    end inside a tile - must give the oracle's images and PCM whatever the tile size, with and without
+    caller-held state, and truncated images must decode like the reference's block walk."""
+    rng = np.random.default_rng(kbytes * 7 + bits)
+    lens = [1, 3, 4, 5, 9000, 2, 700, 12000] + [int(v) for v in rng.integers(1, 4000, 22)]
+    kinds = ["music", "noise", "nyquist"]
+    pcms = [synth_pcm(1, n, channels, seed=300 + i, kind=kinds[i % 3])[0] for i, n in enumerate(lens)]
+    param = make_parameter(channels, bits, mbs, 48000, ms, trials)
+    want = [ob.encode(p, bits, mbs, 48000, ms, trials) for p in pcms]
+    try:
+        engine.set_tile_kbytes(kbytes)
+        images = engine.encode_host(pcms, param)
+        for i, (img, w) in enumerate(zip(images, want)):
+            assert img == w, (i, lens[i])
+        decoded = engine.decode_host(images)
+        for i, d in enumerate(decoded):
+            assert np.array_equal(d, ob.decode(want[i])[0]), (i, lens[i])
+        # caller-held state across two calls (the reference's reused handle, src/aad_encoder.c:853-886)
+        state = np.zeros(len(pcms) * channels, dtype=LANE_STATE_DTYPE)
+        lanes = [ob.fresh_lanes(channels) for _ in pcms]
+        for k in range(2):
+            state["stepsize_index"] = 0
+            images = engine.encode_host(pcms, param, state=state)
+            for i, p in enumerate(pcms):
+                assert images[i] == ob.encode(p, bits, mbs, 48000, ms, trials, lanes=lanes[i], reset_idx=True), (k, i)
+                for c in range(channels):
+                    assert list(state[i * channels + c]["weight"]) == list(lanes[i][c].w), (k, i, c)
+                    assert int(state[i * channels + c]["stepsize_index"]) == lanes[i][c].idx
+        # images that end early: inside a block header is an error, anywhere else the walk stops
+        from aad_amd.engine import parse_header
+        head, bs = 18 * channels, parse_header(want[0][:31]).block_size
+
+        def cut_at(w, drop):
+            n = max(31 + head, len(w) - drop)
+            inside = (n - 31) % bs
+            if 0 < inside < head:
+                n += head - inside
+            return w[: min(n, len(w))]
+        cut = [cut_at(w, 37 * (i % 5)) for i, w in enumerate(want)]
+        engine.set_tile_kbytes(0)
+        whole = engine.decode_host(cut)
+        engine.set_tile_kbytes(kbytes)
+        tiled = engine.decode_host(cut)
+        for i, (x, y) in enumerate(zip(tiled, whole)):
+            assert np.array_equal(x, y), (i, lens[i])
+    finally:
+        engine.set_tile_kbytes(0)
+
+
 def test_state_carry_matches_oracle(engine, mapping):
     """encoder state in/out == the reference's reused-handle behaviour (src/aad_encoder.c:853-886)"""
     ch, streams = 2, 5
