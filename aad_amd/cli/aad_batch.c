@@ -23,12 +23,15 @@
  * Partitioning: inputs are sorted by size and dealt longest-first onto the
  * least-loaded device, O(n log n); sizes come from stat(), nothing is read for it.  Each device
  * slot is a pipeline of three threads joined by two-deep queues -
- *     reader : loads the slot's files in waves of <= 64 MB, parses headers, converts 8/24/32-bit
+ *     reader : loads the slot's files in waves of <= 512 MB, parses headers, converts 8/24/32-bit
  *              PCM to the codec's int16 by the reference's top-16-bit rule (src/main.c:175-179)
  *     device : one AADHip_*Batch call per format group of a wave (context, stream and pinned
  *              staging of its own; no traffic between devices)
  *     writer : writes the wave's outputs and releases its memory
- * - so file reads, device work and file writes of consecutive waves overlap.
+ * - so file reads, device work and file writes of consecutive waves overlap.  Waves are large on
+ * purpose: an encoder launch takes about `blocks of the longest file` x 64 us however many files it
+ * holds (the blocks of a file are chained), so the more long files share a wave the better; the
+ * library cuts the wave into tiles that fit its pinned staging blocks by itself.
  *
  * Output names are OUTDIR/<stem><ext>; two inputs with the same stem would overwrite each other,
  * so that is refused up front.  Every output is byte-identical to what the reference CLI writes
@@ -45,7 +48,7 @@
 #include "../../include/aad_wav.h"
 
 #define MAX_DEVICES 16
-#define WAVE_BYTES_DEFAULT (64ull << 20) /* input bytes per wave of one device slot ($AAD_BATCH_WAVE_BYTES overrides: tests) */
+#define WAVE_BYTES_DEFAULT (512ull << 20) /* input bytes per wave of one device slot ($AAD_BATCH_WAVE_BYTES overrides: tests) */
 #define WAVE_FILES 8192
 #define QUEUE_DEPTH 2
 
