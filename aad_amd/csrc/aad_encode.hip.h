@@ -312,7 +312,7 @@ struct EncodeArgs {
    * that block along. */
   uint32_t lead_frames;
   UniformLayout uni;
-  uint8_t header_template[32]; /* 31-byte file header with num_samples = 0 */
+  alignas(4) uint8_t header_template[32]; /* 31-byte file header with num_samples = 0 */
 };
 
 /* sample i of channel c of a stream, after the optional L/R -> M/S transform
@@ -407,7 +407,10 @@ __device__ __forceinline__ void store_be16(uint8_t *p, uint32_t v)
 
 /* block header of one channel - reference src/aad_encoder.c:619-655.  Drops the weight bits the
  * 16-bit header fields cannot carry from the lane's own state as well. */
-__device__ __forceinline__ void write_block_header(Lane &L, uint8_t *p, bool do_store)
+/* defer3: leave the last three bytes (low byte of weight 3, history 3) unwritten and return them, lowest
+ * address in the low byte - the dense stereo encoder writes them with the first code bytes, which
+ * share their 64-byte granule (see run_block) */
+__device__ __forceinline__ uint32_t write_block_header(Lane &L, uint8_t *p, bool do_store, bool defer3 = false)
 {
   auto wabs = [](int32_t w) { const int32_t m = w >> 31; return (int32_t)(((uint32_t)w ^ (uint32_t)m) - (uint32_t)m); };
   const int32_t maxabs = max(max(max(wabs(L.w0), wabs(L.w1)), max(wabs(L.w2), wabs(L.w3))), 0);
@@ -417,16 +420,25 @@ __device__ __forceinline__ void write_block_header(Lane &L, uint8_t *p, bool do_
   L.w1 &= mask;
   L.w2 &= mask;
   L.w3 &= mask;
-  if (!do_store) return;
-  store_be16(p, ((((uint32_t)(L.idxb - kIdxBias)) << 4) & 0xFFFFu) | ((uint32_t)shift & 0xFu));
-  store_be16(p + 2, (uint32_t)(L.w0 >> shift));
-  store_be16(p + 4, (uint32_t)L.h0);
-  store_be16(p + 6, (uint32_t)(L.w1 >> shift));
-  store_be16(p + 8, (uint32_t)L.h1);
-  store_be16(p + 10, (uint32_t)(L.w2 >> shift));
-  store_be16(p + 12, (uint32_t)L.h2);
-  store_be16(p + 14, (uint32_t)(L.w3 >> shift));
-  store_be16(p + 16, (uint32_t)L.h3);
+  const uint32_t w3 = (uint32_t)(L.w3 >> shift), h3 = (uint32_t)L.h3;
+  const uint32_t last3 = (w3 & 0xFFu) | (((h3 >> 8) & 0xFFu) << 8) | ((h3 & 0xFFu) << 16);
+  if (!do_store) return last3;
+  /* nine big-endian 16-bit fields, stored two to a dword (any alignment: images start on 16-byte
+   * boundaries at best, headers never do) instead of byte by byte */
+  auto two = [](uint32_t first, uint32_t second) { return perm(second, first, 0x04050001); };
+  const uint32_t f0 = ((((uint32_t)(L.idxb - kIdxBias)) << 4) & 0xFFFFu) | ((uint32_t)shift & 0xFu);
+  reinterpret_cast<U32 *>(p)->v = two(f0, (uint32_t)(L.w0 >> shift));
+  reinterpret_cast<U32 *>(p + 4)->v = two((uint32_t)L.h0, (uint32_t)(L.w1 >> shift));
+  reinterpret_cast<U32 *>(p + 8)->v = two((uint32_t)L.h1, (uint32_t)(L.w2 >> shift));
+  const uint32_t d3 = two((uint32_t)L.h2, w3);
+  if (defer3) {
+    reinterpret_cast<U16 *>(p + 12)->v = (uint16_t)d3;
+    p[14] = (uint8_t)(w3 >> 8);
+  } else {
+    reinterpret_cast<U32 *>(p + 12)->v = d3;
+    store_be16(p + 16, h3);
+  }
+  return last3;
 }
 
 /* Write the packed codes of one 16-sample chunk.  w[]: big-endian code words of this lane's
@@ -470,6 +482,10 @@ __device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w
   }
 }
 
+/* the dense stereo 4-bit encode pass stores its codes four chunks at a time (run_block) */
+template <int BITS, int CHF, bool EMIT>
+constexpr bool kBurstStores = EMIT && CHF == 2 && BITS == 4;
+
 /*
  * One pass of the recurrence over the coded samples of a block: samples [first+4, first+n) of
  * channel c, history already seeded.  EMIT = the real encode pass (codes packed and stored under
@@ -481,13 +497,23 @@ __device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w
  */
 template <int BITS, int CHF, bool MS, bool QUAD, bool EMIT, typename S>
 __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t ch,
-                                             uint32_t c, bool writer, uint8_t *body, const char *lds, int32_t &last_qd)
+                                             uint32_t c, bool writer, uint8_t *body, const char *lds, int32_t &last_qd,
+                                             bool defer3 = false, uint32_t deferred = 0)
 {
   constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
   const uint32_t unit_stride = UB * ch;
   const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
   int64_t sq = 0;
   uint32_t done = 0;
+  /* kBurstStores: what the chunk loop leaves for the end of the block */
+  u32x2 burst_r0 = {0, 0}, burst_r1 = {0, 0}, burst_r2 = {0, 0};
+  uint32_t burst_rest = 0, burst_carry = deferred;
+  uint8_t *burst_gp = body + 8u * c;
+  auto put = [](uint8_t *at, u32x2 v) { reinterpret_cast<U32x2 *>(at)->v = v; };
+  auto put_carry = [](uint8_t *at, uint32_t three) { /* at: the granule's first byte */
+    reinterpret_cast<U16 *>(at)->v = (uint16_t)three;
+    at[2] = (uint8_t)(three >> 16);
+  };
   {
     using CS = ChunkSamples<CHF, MS>;
     const uint32_t full = coded / kChunk;
@@ -638,6 +664,66 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         if (k + 1 < full) one(k + 1, xn, x);
       }
       done = full * kChunk;
+    } else if constexpr (kBurstStores<BITS, CHF, EMIT>) {
+      /* Dense stereo 4-bit, the saturated BASELINE shape.  A pair of lanes produces 16 code bytes per
+       * chunk; stored chunk by chunk, the four stores that fill a 64-byte granule are a chunk's worth of
+       * time apart (microseconds on a full chip), the granule leaves the L2 in between and every store
+       * reaches memory as a write of its own: WRITE_SIZE was 4.0x the code bytes.  So the pieces of FOUR
+       * chunks are kept in registers and stored back to back (the loop is unrolled by four).  Code
+       * bytes start 67 bytes into an image (31 file + 36 block header): with 64-byte aligned images and
+       * block sizes every group of 64 code bytes sits 3 bytes into its granule and its last 3 bytes
+       * belong to the next one - those (and, at the start of a block, the last 3 bytes of the block
+       * header, which share the first code granule) wait in `carry` on the channel-1 lane and are
+       * stored with the next group.  defer3 says the block is laid out like that (per lane). */
+      constexpr bool PK = !MS;
+      constexpr int kN = PK ? kChunk / 2 : kChunk;
+      const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
+      uint8_t *gp = body + 8u * c; /* this lane's half of the group's first chunk */
+      uint32_t carry = deferred;
+      auto chunk = [&](uint32_t k) -> u32x2 {
+        int32_t x[kN];
+#pragma unroll
+        for (int j = 0; j < kN; j++) x[j] = PK ? (int32_t)next.pair(j, pair_sel) : next.get(j, c);
+        if (k + 1 < full) xp += (uint64_t)kChunk * ch; /* unconditional prefetch, see below */
+        next.load(xp, ch, c);
+        uint32_t w[2] = {0, 0};
+        encode_chunk16<BITS, EMIT, PK>(L, x, lds, w, last_qd, sq);
+        next.touch();
+        /* lane 0 keeps the first half of the pair's sixteen bytes (word 0 of both channels), lane 1 the second */
+        const uint32_t send = c ? w[0] : w[1], keep = c ? w[1] : w[0];
+        const uint32_t recv = pair_swap<false>(send, c);
+        const uint32_t A = c ? recv : keep, B = c ? keep : recv;
+        u32x2 v;
+        v.x = perm(A, B, 0x02060307);
+        v.y = perm(A, B, 0x00040105);
+        return v;
+      };
+      uint32_t k = 0;
+      for (; k + 4 <= full; k += 4, gp += 4 * kOutStride * 2) {
+        const u32x2 p0 = chunk(k), p1 = chunk(k + 1), p2 = chunk(k + 2), p3 = chunk(k + 3);
+        if (defer3) put_carry(gp - 11, carry); /* channel-1 lane: its piece starts 8 + 3 bytes into the granule */
+        put(gp, p0);
+        put(gp + 16, p1);
+        put(gp + 32, p2);
+        if (defer3) { /* bytes 59..63 of the granule now, the last three with the next group */
+          reinterpret_cast<U32 *>(gp + 48)->v = p3.x;
+          gp[52] = (uint8_t)p3.y;
+          carry = p3.y >> 8;
+        } else {
+          put(gp + 48, p3);
+        }
+      }
+      /* the one to three chunks left over: encoded now, stored together with the tail's bytes at the
+       * end of the block (below) - r2 is the last of them */
+      burst_rest = full - k;
+      for (uint32_t j = 0; j < burst_rest; j++) {
+        burst_r0 = burst_r1;
+        burst_r1 = burst_r2;
+        burst_r2 = chunk(k + j);
+      }
+      burst_gp = gp;
+      burst_carry = carry;
+      done = full * kChunk;
     } else {
       /* mono / stereo without M/S: the samples stay packed two to a dword (see encode_chunk16) */
       constexpr bool PK = CHF != 0 && !MS;
@@ -673,7 +759,27 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
     }
   }
 
-  if (EMIT) { /* tail units: samples past n are zero padding - reference :592-593 */
+  if constexpr (kBurstStores<BITS, CHF, EMIT> && !QUAD) {
+    /* tail units (one byte per lane and unit, at most seven) are collected and stored with what the
+     * chunk loop left over, back to back: the block's last granule is written once, not unit by unit */
+    uint64_t tail = 0;
+    uint32_t units = 0;
+    for (uint32_t i = done; i < coded; i += US, units++) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < US; k++) {
+        const int32_t x = i + k < coded ? src.at(first + kTaps + i + k) : 0;
+        acc = (acc << BITS) | encode_step<BITS>(L, x, lds, last_qd);
+      }
+      tail |= (uint64_t)(acc & 0xFFu) << (8 * units);
+    }
+    if (defer3) put_carry(burst_gp - 11, burst_carry); /* what the last whole group (or the header) left */
+    if (burst_rest == 3) put(burst_gp, burst_r0);
+    if (burst_rest >= 2) put(burst_gp + 16 * (burst_rest - 2), burst_r1);
+    if (burst_rest >= 1) put(burst_gp + 16 * (burst_rest - 1), burst_r2);
+    uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
+    for (uint32_t u = 0; u < units; u++, up += unit_stride, tail >>= 8) up[0] = (uint8_t)tail;
+  } else if (EMIT) { /* tail units: samples past n are zero padding - reference :592-593 */
     uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
     for (uint32_t i = done; i < coded; i += US, up += unit_stride) {
       uint32_t acc = 0;
@@ -839,11 +945,17 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 
   if (c == 0 && writer) { /* file header - reference src/aad_encoder.c:190-214 */
     const uint32_t encoded = total - a.lead_frames;
-    for (int i = 0; i < kFileHeaderBytes; i++) out[i] = a.header_template[i];
-    out[14] = (uint8_t)(encoded >> 24);
-    out[15] = (uint8_t)(encoded >> 16);
-    out[16] = (uint8_t)(encoded >> 8);
-    out[17] = (uint8_t)encoded;
+    /* 31 bytes as seven dwords and three bytes; the sample count is big-endian in bytes 14..17 */
+    const uint32_t *t = reinterpret_cast<const uint32_t *>(a.header_template);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      uint32_t d = t[i];
+      if (i == 3) d = (d & 0x0000FFFFu) | ((encoded >> 24) << 16) | (((encoded >> 16) & 0xFFu) << 24);
+      if (i == 4) d = (d & 0xFFFF0000u) | ((encoded >> 8) & 0xFFu) | ((encoded & 0xFFu) << 8);
+      reinterpret_cast<U32 *>(out + 4 * i)->v = d;
+    }
+    reinterpret_cast<U16 *>(out + 28)->v = (uint16_t)t[7];
+    out[30] = (uint8_t)(t[7] >> 16);
   }
 
   uint64_t block_off = kFileHeaderBytes;
@@ -859,13 +971,16 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
       if constexpr (QUAD) F = from_quad<kEncTM>(L); else F = L;
     }
     seed_history(F, src, first, n);
-    write_block_header(F, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh, writer);
-    if constexpr (QUAD) L = to_quad(F, tap); else L = F;
     uint8_t *body = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch;
+    /* dense stereo 4-bit: code bytes 3 bytes into a 64-byte granule - the channel-1 lane holds the
+     * header's last three bytes back for the first burst of code bytes (run_block) */
+    const bool defer3 = !QUAD && kBurstStores<BITS, CHF, true> && c == 1 && (reinterpret_cast<uintptr_t>(body) & 63u) == 3u;
+    const uint32_t deferred = write_block_header(F, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh, writer, defer3);
+    if constexpr (QUAD) L = to_quad(F, tap); else L = F;
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
     /* dual: role 1 runs the encode pass as well (it holds the same state; only role 0 stores),
      * which also leaves it with the right state for the next block */
-    (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd);
+    (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd, defer3, deferred);
     if constexpr (QUAD) F = from_quad<kEncTM>(L); else F = L;
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   }

@@ -119,11 +119,12 @@ class Engine:
     # ---- uniform batches (every stream the same length) -----------------------------------
     def uniform_encode_plan(self, param, num_streams, num_samples):
         """Stream table for a [streams, samples, channels] int16 tensor and a [streams, stride]
-        uint8 output; stride = encoded size rounded up to 16 bytes."""
+        uint8 output; stride = encoded size rounded up to 64 bytes (images on 64-byte boundaries let the
+        dense stereo encoder store whole granules - aad_encode.hip.h run_block)."""
         size = self.encoded_size(param, num_samples)
         if size == 0:
             raise ApiError("AADHip_CalculateEncodedSize", AADApiResult.INVALID_FORMAT)
-        stride = _round_up(size, 16)
+        stride = _round_up(size, 64)
         d = np.zeros(num_streams, dtype=STREAM_DESC_DTYPE)
         i = np.arange(num_streams, dtype=np.uint64)
         d["pcm_offset"] = i * np.uint64(num_samples * param.num_channels)
