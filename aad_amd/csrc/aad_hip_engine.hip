@@ -63,6 +63,7 @@ struct AADHipContext {
    * host fills chunk k+1's input block and drains chunk k-1's output block */
   Staging in[2], out[2];
   hipEvent_t chunk_done[2];
+  hipEvent_t piece_done[3]; /* the earlier pieces of a one-tile decode's output copy */
   /* a cut batch runs its copies on streams of their own, so that tile k+1 goes up and tile k-1
    * comes down while tile k computes */
   hipStream_t up_stream, down_stream;
@@ -573,6 +574,8 @@ void AADHip_ContextDestroy(struct AADHipContext *ctx)
         staging_release(ctx->in[b]);
         staging_release(ctx->out[b]);
         if (ctx->have_events) (void)hipEventDestroy(ctx->chunk_done[b]);
+        if (ctx->have_events && b == 0)
+          for (int i = 0; i < 3; i++) (void)hipEventDestroy(ctx->piece_done[i]);
         if (ctx->have_pipeline) {
           (void)hipEventDestroy(ctx->uploaded[b]);
           (void)hipEventDestroy(ctx->computed[b]);
@@ -820,18 +823,19 @@ void staging_pool_main(StagingPool *p, unsigned index)
 /* Run body(first, last) over [0, count) cut into contiguous ranges of about equal cost, one per thread
  * (the caller's included).  `prefix` has count + 1 entries: the running cost. */
 template <class Body>
-void staged_ranges(AADHipContext *ctx, uint32_t count, const std::vector<uint64_t> &prefix, Body body)
+void staged_span(AADHipContext *ctx, uint32_t first, uint32_t count, const std::vector<uint64_t> &prefix, Body body)
 {
-  const unsigned want = count < 2 || prefix[count] < kParallelStagingAbove ? 1u : staging_threads(ctx);
+  const uint64_t base = prefix[first];
+  const unsigned want = count - first < 2 || prefix[count] - base < kParallelStagingAbove ? 1u : staging_threads(ctx);
   if (want <= 1) {
-    body(0u, count);
+    body(first, count);
     return;
   }
   if (ctx->pool != nullptr && ctx->pool->threads.size() + 1 != want) staging_pool_stop(ctx);
   if (ctx->pool == nullptr) {
     ctx->pool = new (std::nothrow) StagingPool();
     if (ctx->pool == nullptr) {
-      body(0u, count);
+      body(first, count);
       return;
     }
     for (unsigned t = 1; t < want; t++) ctx->pool->threads.emplace_back(staging_pool_main, ctx->pool, t);
@@ -840,8 +844,9 @@ void staged_ranges(AADHipContext *ctx, uint32_t count, const std::vector<uint64_
   const unsigned parts = (unsigned)p->threads.size() + 1;
   auto bound = [&](unsigned t) -> uint32_t { /* first item of part t */
     if (t >= parts) return count;
-    const uint64_t target = prefix[count] / parts * t;
-    uint32_t lo = 0, hi = count;
+    if (t == 0) return first;
+    const uint64_t target = base + (prefix[count] - base) / parts * t;
+    uint32_t lo = first, hi = count;
     while (lo < hi) {
       const uint32_t mid = lo + (hi - lo) / 2;
       if (prefix[mid] < target) lo = mid + 1; else hi = mid;
@@ -864,6 +869,33 @@ void staged_ranges(AADHipContext *ctx, uint32_t count, const std::vector<uint64_
   p->done.wait(g, [&] { return p->pending == 0; });
 }
 
+template <class Body>
+void staged_ranges(AADHipContext *ctx, uint32_t count, const std::vector<uint64_t> &prefix, Body body)
+{
+  staged_span(ctx, 0u, count, prefix, body);
+}
+
+/* A batch that travels as ONE tile has nothing to overlap with, so its big copy is cut into pieces
+ * instead: encode sends piece p up while the host fills piece p + 1, decode drains piece p while
+ * piece p + 1 comes down.  Item index where each piece ends, by running bytes. */
+constexpr uint32_t kMaxPieces = 4;
+constexpr uint64_t kPieceBytes = 1ull << 20;
+
+uint32_t cut_pieces(const std::vector<uint64_t> &prefix, uint32_t count, bool wanted, uint32_t *end)
+{
+  const uint64_t total = prefix[count];
+  uint32_t pieces = wanted ? (uint32_t)(total / kPieceBytes) : 1u;
+  pieces = pieces < 1 ? 1 : (pieces > kMaxPieces ? kMaxPieces : pieces);
+  uint32_t at = 0, made = 0;
+  for (uint32_t p = 1; p < pieces; p++) {
+    const uint64_t target = total / pieces * p;
+    while (at < count && prefix[at] < target) at++;
+    if (at > (made ? end[made - 1] : 0u) && at < count) end[made++] = at;
+  }
+  end[made++] = count;
+  return made;
+}
+
 bool ensure_events(AADHipContext *ctx)
 {
   if (ctx->have_events) return true;
@@ -872,6 +904,13 @@ bool ensure_events(AADHipContext *ctx)
     (void)hipEventDestroy(ctx->chunk_done[0]);
     return false;
   }
+  for (int i = 0; i < 3; i++)
+    if (!hip_ok(ctx, hipEventCreateWithFlags(&ctx->piece_done[i], hipEventDisableTiming), "hipEventCreate")) {
+      for (int k = 0; k < i; k++) (void)hipEventDestroy(ctx->piece_done[k]);
+      (void)hipEventDestroy(ctx->chunk_done[0]);
+      (void)hipEventDestroy(ctx->chunk_done[1]);
+      return false;
+    }
   ctx->have_events = true;
   return true;
 }
@@ -1017,6 +1056,7 @@ struct Flight {
   std::vector<uint64_t> cost;        /* running bytes over items: [items + 1] */
   std::vector<uint32_t> state_order; /* encode, last tile of a group: the group's order, else empty */
   uint64_t state_src = 0;
+  uint32_t pieces = 1, piece_end[4] = {0, 0, 0, 0}; /* decode: item index where each piece of the output copy ends */
 };
 
 bool batch_is_cut(const AADHipContext *ctx, uint64_t total_bytes) { return ctx->tile_bytes > 0 || total_bytes > kCutAbove; }
@@ -1068,8 +1108,9 @@ AADApiResult encode_host(AADHipContext *ctx, const struct AADEncodeParameter *pa
   if (!guard.ok || !ensure_events(ctx)) return AAD_APIRESULT_NG;
 
   TilePlanner planner(blocks.data(), num_streams, (uint64_t)spb * ch * sizeof(int16_t) + h.block_size, tile_budget(ctx, total));
-  if (batch_is_cut(ctx, total) && !ensure_pipeline(ctx)) return AAD_APIRESULT_NG;
-  const Route route = route_for(ctx, batch_is_cut(ctx, total));
+  const bool piped = batch_is_cut(ctx, total);
+  if (piped && !ensure_pipeline(ctx)) return AAD_APIRESULT_NG;
+  const Route route = route_for(ctx, piped);
   Flight flight[2];
   std::vector<AADHipStreamDesc> table;
   std::vector<uint64_t> fill_cost;
@@ -1164,11 +1205,22 @@ AADApiResult encode_host(AADHipContext *ctx, const struct AADEncodeParameter *pa
     if (state_in) /* every stream of a group is alive in its first tile: n == group_size */
       for (uint32_t k = 0; k < n; k++)
         memcpy(hin + table_bytes + sizeof(AADHipLaneState) * (size_t)k * ch, state + (size_t)order[k] * ch, sizeof(AADHipLaneState) * ch);
-    staged_ranges(ctx, n, fill_cost, [&](uint32_t lo, uint32_t hi) {
-      for (uint32_t k = lo; k < hi; k++)
-        fill(order[k], (uint32_t)(step.block0 * spb - lead), table[k].num_samples, reinterpret_cast<int16_t *>(hin + pcm_off) + table[k].pcm_offset);
-    });
-    if (!hip_ok(ctx, hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, route.up), "H2D block")) break;
+    {
+      uint32_t piece_end[kMaxPieces];
+      const uint32_t pieces = cut_pieces(fill_cost, n, !piped, piece_end);
+      size_t sent = 0;
+      bool ok = true;
+      for (uint32_t p = 0, lo = 0; ok && p < pieces; lo = piece_end[p++]) {
+        staged_span(ctx, lo, piece_end[p], fill_cost, [&](uint32_t x, uint32_t y) {
+          for (uint32_t k = x; k < y; k++)
+            fill(order[k], (uint32_t)(step.block0 * spb - lead), table[k].num_samples, reinterpret_cast<int16_t *>(hin + pcm_off) + table[k].pcm_offset);
+        });
+        const size_t upto = p + 1 == pieces ? in_bytes : pcm_off + (size_t)fill_cost[piece_end[p]];
+        ok = hip_ok(ctx, hipMemcpyAsync(din + sent, hin + sent, upto - sent, hipMemcpyHostToDevice, route.up), "H2D block");
+        sent = upto;
+      }
+      if (!ok) break;
+    }
     if (!hop(ctx, ctx->uploaded[b], route.up, route.run)) break;
     aad::LaneStateRecord *d_state = static_cast<aad::LaneStateRecord *>(ctx->d_state);
     a.streams = reinterpret_cast<const aad::StreamDesc *>(din);
@@ -1233,8 +1285,9 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
   if (decoded_frames) memset(decoded_frames, 0, sizeof(uint32_t) * num_streams);
 
   TilePlanner planner(blocks.data(), num_streams, (uint64_t)spb * ch * sizeof(int16_t) + bs, tile_budget(ctx, total));
-  if (batch_is_cut(ctx, total) && !ensure_pipeline(ctx)) return AAD_APIRESULT_NG;
-  const Route route = route_for(ctx, batch_is_cut(ctx, total));
+  const bool piped = batch_is_cut(ctx, total);
+  if (piped && !ensure_pipeline(ctx)) return AAD_APIRESULT_NG;
+  const Route route = route_for(ctx, piped);
   Flight flight[2];
   uint64_t sequence = 0;
 
@@ -1242,16 +1295,21 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
     Flight &f = flight[b];
     if (!f.active) return true;
     f.active = false;
-    if (!hip_ok(ctx, hipEventSynchronize(ctx->chunk_done[b]), "hipEventSynchronize")) return false;
     const int16_t *out = static_cast<const int16_t *>(ctx->out[b].host);
-    staged_ranges(ctx, (uint32_t)f.items.size(), f.cost, [&](uint32_t lo, uint32_t hi) {
-      for (uint32_t k = lo; k < hi; k++) {
-        const Delivery &d = f.items[k];
-        if (d.count) drain(d.stream, (uint32_t)d.dst, out + d.src, (uint32_t)d.count);
-        if (decoded_frames) decoded_frames[d.stream] += (uint32_t)d.count; /* one item per stream and tile */
-      }
-    });
-    return true;
+    bool ok = true;
+    for (uint32_t p = 0, first = 0; p < f.pieces; first = f.piece_end[p++]) {
+      /* every piece is waited for, also after a failure: the buffers must be idle on return */
+      if (!hip_ok(ctx, hipEventSynchronize(p + 1 == f.pieces ? ctx->chunk_done[b] : ctx->piece_done[p]), "hipEventSynchronize")) ok = false;
+      if (!ok) continue;
+      staged_span(ctx, first, f.piece_end[p], f.cost, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t k = lo; k < hi; k++) {
+          const Delivery &d = f.items[k];
+          if (d.count) drain(d.stream, (uint32_t)d.dst, out + d.src, (uint32_t)d.count);
+          if (decoded_frames) decoded_frames[d.stream] += (uint32_t)d.count; /* one item per stream and tile */
+        }
+      });
+    }
+    return ok;
   };
 
   AADApiResult rc = AAD_APIRESULT_OK;
@@ -1315,8 +1373,20 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
     if ((reinterpret_cast<uintptr_t>(a.pcm) & 63u) != 0) a.stream_stores = 0;
     if (run_decode(ctx, a) != AAD_APIRESULT_OK) break;
     if (!hop(ctx, ctx->computed[b], route.run, route.down)) break;
-    if (out_bytes && !hip_ok(ctx, hipMemcpyAsync(ctx->out[b].host, ctx->out[b].dev, out_bytes, hipMemcpyDeviceToHost, route.down), "D2H block")) break;
-    if (!hip_ok(ctx, hipEventRecord(ctx->chunk_done[b], route.down), "hipEventRecord")) break;
+    {
+      f.pieces = cut_pieces(f.cost, n, !piped, f.piece_end);
+      size_t got = 0;
+      bool ok = true;
+      for (uint32_t p = 0; ok && p < f.pieces; p++) {
+        const size_t upto = p + 1 == f.pieces ? out_bytes : (size_t)f.cost[f.piece_end[p]];
+        if (upto > got)
+          ok = hip_ok(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->out[b].host) + got, static_cast<uint8_t *>(ctx->out[b].dev) + got,
+                                         upto - got, hipMemcpyDeviceToHost, route.down), "D2H block");
+        got = upto;
+        ok = ok && hip_ok(ctx, hipEventRecord(p + 1 == f.pieces ? ctx->chunk_done[b] : ctx->piece_done[p], route.down), "hipEventRecord");
+      }
+      if (!ok) break;
+    }
     f.sequence = sequence++;
     f.active = true;
     rc = AAD_APIRESULT_OK;

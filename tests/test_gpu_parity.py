@@ -354,6 +354,49 @@ def test_plan_validation_errors(engine):
     assert e.value.code == R.INVALID_FORMAT
 
 
+@pytest.mark.parametrize("kbytes", [0, 4])
+def test_host_batch_errors_leave_nothing_behind(engine, kbytes):
+    """One bad stream fails the whole host-memory call before any tile runs - also when the batch is
+    cut into tiles: an image that ends inside a block header is the reference's INSUFFICIENT_DATA
+    (src/aad_decoder.c:347-349), an output buffer that is too small INSUFFICIENT_BUFFER, and the other
+    streams' outputs stay untouched.  The context keeps working afterwards."""
+    from aad_amd import AADApiResult as R
+    pcms = [synth_pcm(1, 3000 + 100 * i, 2, seed=40 + i)[0] for i in range(6)]
+    param = make_parameter(2, 4, 256, 48000, False, 0)
+    images = [ob.encode(p, 4, 256) for p in pcms]
+    lib, ctx = engine.lib, engine._ctx
+    try:
+        engine.set_tile_kbytes(kbytes)
+        n = len(images)
+        bad = list(images)
+        bad[4] = bad[4][: 31 + 256 * 3 + 20]                     # inside block 3's 36-byte header
+        bufs = [np.frombuffer(b, dtype=np.uint8) for b in bad]
+        outs = [np.full((p.shape[0], 2), 77, dtype=np.int16) for p in pcms]
+        sizes = np.array([len(b) for b in bufs], dtype=np.uint64)
+        caps = np.array([p.shape[0] for p in pcms], dtype=np.uint32)
+        got = np.full(n, 99, dtype=np.uint32)
+        dp = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        pp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        assert lib.AADHip_DecodeBatch(ctx, n, dp, sizes.ctypes.data, pp, caps.ctypes.data, got.ctypes.data) == R.INSUFFICIENT_DATA
+        assert all((o == 77).all() for o in outs)
+        # encode: stream 2's buffer one byte short
+        pcm_c = [np.ascontiguousarray(p) for p in pcms]
+        nsamp = np.array([p.shape[0] for p in pcm_c], dtype=np.uint32)
+        ecaps = np.array([len(b) for b in images], dtype=np.uint64)
+        ecaps[2] -= 1
+        eouts = [np.full(len(b), 0x55, dtype=np.uint8) for b in images]
+        esizes = np.zeros(n, dtype=np.uint64)
+        ip = (C.c_void_p * n)(*[p.ctypes.data for p in pcm_c])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in eouts])
+        assert lib.AADHip_EncodeBatch(ctx, C.byref(param), n, ip, nsamp.ctypes.data, op, ecaps.ctypes.data,
+                                      esizes.ctypes.data, None) == R.INSUFFICIENT_BUFFER
+        assert all((o == 0x55).all() for o in eouts)
+        # and the same context still produces the oracle's bytes
+        assert engine.encode_host(pcms, param) == images
+    finally:
+        engine.set_tile_kbytes(0)
+
+
 def test_reference_cli_linked_against_this_library(tmp_path):
     """the reference's own main.c / wav.c / option parser, compiled from
     its sources in the build container and linked against libaad_hip.so instead of the reference
