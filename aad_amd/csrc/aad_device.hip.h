@@ -111,6 +111,7 @@ __device__ __forceinline__ uint32_t wide_addr(int32_t idxb) { return (uint32_t)i
  * where the unscaled form took one v_and_b32), the deltas come scaled as well. */
 constexpr int kLdsBytesQuadEnc = kLdsWideOff + AAD_STEP_TABLE_LEN * 64;
 constexpr int kIdxScale = 4;
+constexpr int kWideStepShift = 9; /* the encoders' wide records hold step << 9: a 24-bit factor for v_mul_hi_u32_u24 */
 __device__ __forceinline__ uint32_t wide4_addr(int32_t j, uint32_t copy_off) { return ((uint32_t)j & 0x3FC0u) | copy_off; }
 
 /* byte offset of the step index's slot in the dword arrays */

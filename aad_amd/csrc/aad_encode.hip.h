@@ -119,13 +119,13 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
   static_for<0, kChunk>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     /* A */
-    const uint32_t step2 = e.x; /* 2 * step (stage_tables<.., WIDE_STEP_SHIFT = 1>) */
+    const uint32_t step9 = e.x; /* step << kWideStepShift (stage_tables), 24 bits at most */
     const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)), Pack<BITS>::kMagMax);
     const uint32_t m21 = (mag << 1) | 1u;
     const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDelta4Off - 1) + m21); /* 4 * delta */
     __builtin_amdgcn_sched_barrier(0);
     /* B */
-    const int32_t q = (int32_t)(__umul24(step2, m21) >> BITS); /* (step * (2 mag + 1)) >> (BITS - 1) */
+    const int32_t q = (int32_t)(__umul24(step9, m21) >> (BITS - 1 + kWideStepShift)); /* (step * (2 mag + 1)) >> (BITS - 1) */
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
     lms_first(L, qd);
@@ -229,15 +229,16 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     /* A */
     const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)),
                              Pack<BITS>::kMagMax);
-    const uint32_t step2_j = e.x; /* 2 * step (stage_tables<.., WIDE_STEP_SHIFT = 1>) */
+    const uint32_t step9_j = e.x; /* step << kWideStepShift (stage_tables) */
     idxj = min(max(idxj + index_delta_arith_x4<BITS>(mag), kIdxScale * kIdxMin), kIdxScale * kIdxMax);
     e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide4_addr(idxj, copy));
     __builtin_amdgcn_sched_barrier(0);
-    /* B: q = (step * (2 mag + 1)) >> (BITS-1) as ONE high multiply:
-     * (2 step) * ((2 mag + 1) << (32 - BITS)) = step * (2 mag + 1) * 2^(33 - BITS), upper 32 bits.
-     * 2 step < 2^16 and (2 mag + 1) < 2^BITS, so neither factor overflows and the result is exact. */
-    const uint32_t m21s = (mag << (33 - BITS)) | (1u << (32 - BITS));
-    const int32_t q = (int32_t)__umulhi(step2_j, m21s);
+    /* B: q = (step * (2 mag + 1)) >> (BITS-1) as ONE high multiply on the 24-bit multiplier
+     * (v_mul_hi_u32_u24 issues like an add, the 32-bit v_mul_hi_u32 costs a lone wave ~1.5 cycles more):
+     * (step << 9) * ((2 mag + 1) << (24 - BITS)) = step * (2 mag + 1) * 2^(33 - BITS), upper 32 bits of
+     * the 48-bit product.  step < 2^15 and 2 mag + 1 < 2^BITS, so both factors fit 24 bits. */
+    const uint32_t m21s = (mag << (25 - BITS)) | (1u << (24 - BITS));
+    const int32_t q = (int32_t)(uint32_t)(((uint64_t)(step9_j & 0xFFFFFFu) * (uint64_t)(m21s & 0xFFFFFFu)) >> 32); /* v_mul_hi_u32_u24 */
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
     lms_and_shift<kEncTM ? kShiftBankMask : kShiftBitSelect>(L, qd, y);
@@ -908,7 +909,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
   static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytesQuadEnc]; /* dense and quad encoders share the four-copy wide table */
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
-  stage_tables<BITS, true, 1, true>(lds);
+  stage_tables<BITS, true, kWideStepShift, true>(lds);
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   const uint32_t ch = CHF ? CHF : a.channels;

@@ -44,6 +44,8 @@ def test_random_parameter_sets(engine, mapping, seed):
             kind = str(rng.choice(["music", "noise", "nyquist"]))
             pcms = [synth_pcm(1, n, ch, seed=int(rng.integers(0, 1 << 30)), kind=kind)[0] for n in lengths]
             param = make_parameter(ch, bits, mbs, 48000, ms, trials)
+            # the host-memory path as one tile, or cut into groups of streams and tiles of blocks
+            engine.set_tile_kbytes(int(rng.choice([0, 0, 1, 5, 40])))
             try:
                 want = [ob.encode(p, bits, mbs, 48000, ms, trials) for p in pcms]
             except RuntimeError:
@@ -60,6 +62,7 @@ def test_random_parameter_sets(engine, mapping, seed):
                 assert np.array_equal(got, ob.decode(w)[0]), (seed, mapping, ch, bits, ms, trials, mbs, lengths[i])
     finally:
         engine.set_mapping("auto")
+        engine.set_tile_kbytes(0)
 
 
 @pytest.mark.parametrize("mapping", ["dense", "quad", "quad-fused"])
@@ -95,6 +98,13 @@ def test_random_device_resident_plans(engine, mapping, seed):
             pitch_pcm = (max(lengths) * ch + int(rng.integers(0, 9))) if uniform else None
             pitch_dat = (max(sizes) + int(rng.integers(0, 17))) if uniform else None
             order = list(range(streams)) if uniform else list(rng.permutation(streams))
+            granule = bool(rng.integers(0, 2))
+            if granule:
+                # images on 64-byte boundaries: the dense stereo 4-bit encoder then stores whole granules,
+                # holding three bytes back per group (aad_encode.hip.h run_block) - every other draw
+                pad_dat = 0
+                if uniform:
+                    pitch_dat = -(-pitch_dat // 64) * 64
             d = np.zeros(streams, dtype=STREAM_DESC_DTYPE)
             pos_p, pos_d = pad_pcm, pad_dat
             for slot in order:
@@ -102,6 +112,8 @@ def test_random_device_resident_plans(engine, mapping, seed):
                 d["data_size"][slot], d["num_samples"][slot] = sizes[slot], lengths[slot]
                 pos_p += pitch_pcm if uniform else lengths[slot] * ch + int(rng.integers(0, 5))
                 pos_d += pitch_dat if uniform else sizes[slot] + int(rng.integers(0, 7))
+                if granule and not uniform:
+                    pos_d = -(-pos_d // 64) * 64
             flat = np.zeros(pos_p + 64, dtype=np.int16)
             for i, p in enumerate(pcms):
                 o = int(d["pcm_offset"][i])
