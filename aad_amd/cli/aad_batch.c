@@ -23,45 +23,56 @@
  * Partitioning: inputs are sorted by size and dealt longest-first onto the
  * least-loaded device, O(n log n); sizes come from stat(), nothing is read for it.  Each device
  * slot is a pipeline of three threads joined by two-deep queues -
- *     reader : loads the slot's files in waves of <= 512 MB, parses headers, converts 8/24/32-bit
- *              PCM to the codec's int16 by the reference's top-16-bit rule (src/main.c:175-179)
+ *     reader : maps the slot's files (read-only, no copy) in waves, parses headers, converts
+ *              8/24/32-bit PCM to the codec's int16 by the reference's top-16-bit rule (src/main.c:175-179)
  *     device : one AADHip_*Batch call per format group of a wave (context, stream and pinned
- *              staging of its own; no traffic between devices)
- *     writer : writes the wave's outputs and releases its memory
- * - so file reads, device work and file writes of consecutive waves overlap.  Waves are large on
- * purpose: an encoder launch takes about `blocks of the longest file` x 64 us however many files it
- * holds (the blocks of a file are chained), so the more long files share a wave the better; the
- * library cuts the wave into tiles that fit its pinned staging blocks by itself.
+ *              staging of its own; no traffic between devices).  Every output file is created at
+ *              its final size and mapped, so the library's staging threads copy results straight
+ *              into the page cache (a buffer plus a write() pass by one thread was the slowest
+ *              stage of -d, whose output is four times its input)
+ *     writer : closes the wave's outputs (trims or removes them after a failure) and unmaps its inputs
+ * - so header parsing, device work and file completion of consecutive waves overlap.  A wave is
+ * up to 8192 files or 64 GB (mapped files cost page cache, not process memory): an encoder launch
+ * takes about `blocks of the longest file` x 64 us (x3 with the default trial search) however many
+ * files it holds - the blocks of a file are chained - so the more long files share a wave the
+ * better; the library cuts the wave into tiles that fit its pinned staging blocks by itself.
  *
  * Output names are OUTDIR/<stem><ext>; two inputs with the same stem would overwrite each other,
  * so that is refused up front.  Every output is byte-identical to what the reference CLI writes
  * for the same input.  Host C only; all codec work happens in libaad_hip.so.
  */
 #define _POSIX_C_SOURCE 200809L
+#include <fcntl.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/aad_hip.h"
 #include "../../include/aad_wav.h"
 
 #define MAX_DEVICES 16
-#define WAVE_BYTES_DEFAULT (512ull << 20) /* input bytes per wave of one device slot ($AAD_BATCH_WAVE_BYTES overrides: tests) */
+#define WAVE_BYTES_DEFAULT (64ull << 30) /* bytes a wave of one device slot spans, max(inputs, outputs) ($AAD_BATCH_WAVE_BYTES overrides: tests) */
 #define WAVE_FILES 8192
 #define QUEUE_DEPTH 2
 
 struct File {
   const char *path;
   uint64_t disk_size;
-  uint8_t *bytes;             /* file image */
+  uint8_t *bytes;             /* file image: the file itself, mapped read-only (no copy: the library stages straight from the page cache) */
   uint64_t size;
+  int mapped;                 /* bytes came from mmap */
   int16_t *converted;         /* int16 PCM made from 8/24/32-bit input, else NULL */
   struct AADWavInfo wav;      /* WAV-input modes */
   struct AADHeaderInfo head;  /* decode */
-  uint8_t *out;
+  uint8_t *out;               /* where the device stage delivers: inside out_map, or a malloc'd buffer (fallback) */
   uint64_t out_size;
+  uint8_t *out_map;           /* the output FILE, created at its final size and mapped shared: results land in the page cache */
+  uint64_t out_map_size, out_head;
   struct AADHipErrorStats stats;
   int device_slot;
   int done;
@@ -127,7 +138,8 @@ static struct Wave queue_pop(struct Queue *q)
   return w;
 }
 
-static int slurp(struct File *f)
+/* a private, writable copy of a (small) file: the list of inputs */
+static int slurp_copy(struct File *f)
 {
   FILE *fp = fopen(f->path, "rb");
   long n;
@@ -138,6 +150,7 @@ static int slurp(struct File *f)
   }
   f->bytes = (uint8_t *)malloc((size_t)n + 16);
   f->size = (uint64_t)n;
+  f->mapped = 0;
   if (f->bytes == NULL || fread(f->bytes, 1, (size_t)n, fp) != (size_t)n) {
     fclose(fp);
     return 0;
@@ -146,12 +159,50 @@ static int slurp(struct File *f)
   return 1;
 }
 
+/* an input file, mapped read-only */
+static int slurp(struct File *f)
+{
+  struct stat st;
+  const int fd = open(f->path, O_RDONLY);
+  void *m;
+  if (fd < 0) return 0;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+    close(fd);
+    return 0;
+  }
+  f->size = (uint64_t)st.st_size;
+  f->mapped = 0;
+  if (f->size == 0) { /* nothing to map; the parsers refuse it */
+    close(fd);
+    f->bytes = (uint8_t *)calloc(1, 16);
+    return f->bytes != NULL;
+  }
+  m = mmap(NULL, (size_t)f->size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return 0;
+  (void)posix_madvise(m, (size_t)f->size, POSIX_MADV_SEQUENTIAL);
+  f->bytes = (uint8_t *)m;
+  f->mapped = 1;
+  return 1;
+}
+
+static void drop_input(struct File *f)
+{
+  if (f->bytes != NULL) {
+    if (f->mapped) (void)munmap(f->bytes, (size_t)f->size);
+    else free(f->bytes);
+  }
+  f->bytes = NULL;
+  f->mapped = 0;
+}
+
 static void release_file(struct File *f)
 {
-  free(f->bytes);
+  drop_input(f);
   free(f->converted);
-  free(f->out);
-  f->bytes = f->out = NULL;
+  if (f->out_map != NULL) (void)munmap(f->out_map, (size_t)f->out_map_size);
+  else free(f->out);
+  f->out = f->out_map = NULL;
   f->converted = NULL;
 }
 
@@ -165,15 +216,65 @@ static void stem_of(const char *path, const char **start, size_t *len)
   *len = dot && dot != base ? (size_t)(dot - base) : strlen(base);
 }
 
+static int out_path(char *path, size_t cap, const char *outdir, const char *inpath, const char *ext)
+{
+  const char *base;
+  size_t stem;
+  stem_of(inpath, &base, &stem);
+  return snprintf(path, cap, "%s/%.*s%s", outdir, (int)stem, base, ext) < (int)cap;
+}
+
+/* Create the output file at its final size and map it: the library then copies its results straight
+ * into the page cache from its staging threads - no buffer of our own, no write() pass by a single
+ * thread (decode output is four times its input: that pass was the slowest stage).  Leaves
+ * f->out_map NULL when the file system will not do it; the caller then falls back to a buffer. */
+static void map_output(const struct Options *opt, struct File *f, const char *ext, const uint8_t *head, size_t head_size, uint64_t body_size)
+{
+  char path[4096];
+  int fd;
+  void *m;
+  f->out_map = NULL;
+  if (head_size + body_size == 0 || !out_path(path, sizeof(path), opt->outdir, f->path, ext)) return;
+  fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) return;
+  if (ftruncate(fd, (off_t)(head_size + body_size)) != 0) {
+    close(fd);
+    (void)unlink(path);
+    return;
+  }
+  m = mmap(NULL, (size_t)(head_size + body_size), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) {
+    (void)unlink(path);
+    return;
+  }
+  f->out_map = (uint8_t *)m;
+  f->out_map_size = head_size + body_size;
+  f->out_head = head_size;
+  if (head_size) memcpy(f->out_map, head, head_size);
+  f->out = f->out_map + head_size;
+}
+
+/* a mapped output is complete once the device stage is done with it; returns 0 on failure */
+static int finish_mapped(const struct Options *opt, struct File *f, const char *ext, int keep)
+{
+  char path[4096];
+  const uint64_t final_size = f->out_head + f->out_size;
+  int ok = 1;
+  (void)munmap(f->out_map, (size_t)f->out_map_size);
+  f->out_map = f->out = NULL;
+  if (!out_path(path, sizeof(path), opt->outdir, f->path, ext)) return 0;
+  if (!keep) return unlink(path) == 0;
+  if (final_size != f->out_map_size) ok = truncate(path, (off_t)final_size) == 0;
+  return ok;
+}
+
 static int write_out(const char *outdir, const char *inpath, const char *ext, const uint8_t *head, size_t head_size,
                      const uint8_t *body, size_t body_size)
 {
   char path[4096];
-  const char *base;
-  size_t stem;
   FILE *fp;
-  stem_of(inpath, &base, &stem);
-  if (snprintf(path, sizeof(path), "%s/%.*s%s", outdir, (int)stem, base, ext) >= (int)sizeof(path)) return 0;
+  if (!out_path(path, sizeof(path), outdir, inpath, ext)) return 0;
   fp = fopen(path, "wb");
   if (fp == NULL) return 0;
   if ((head_size && fwrite(head, 1, head_size, fp) != head_size) || fwrite(body, 1, body_size, fp) != body_size) {
@@ -221,8 +322,7 @@ static int load_file(const struct Options *opt, struct File *f)
       fprintf(stderr, "aad_batch: %s: unsupported PCM width %u\n", f->path, (unsigned)f->wav.bits_per_sample);
       return 0;
     }
-    free(f->bytes); /* only the converted samples are needed from here on */
-    f->bytes = NULL;
+    drop_input(f); /* only the converted samples are needed from here on */
   }
   return 1;
 }
@@ -236,8 +336,11 @@ static void *reader_main(void *arg)
   while (i < s->nfiles && !w.failed) {
     uint64_t bytes = 0;
     w.first = i;
-    while (i < s->nfiles && (i == w.first || (bytes + s->files[i]->disk_size <= s->opt->wave_bytes && i - w.first < WAVE_FILES))) {
-      bytes += s->files[i]->disk_size;
+    /* a wave is sized by what it holds in memory at once: its inputs are mapped, its outputs are
+     * allocated - a quarter of the input for -e, up to four times the input for -d */
+    const uint64_t weight = s->opt->mode == 'd' ? 4 : 1;
+    while (i < s->nfiles && (i == w.first || (bytes + weight * s->files[i]->disk_size <= s->opt->wave_bytes && i - w.first < WAVE_FILES))) {
+      bytes += weight * s->files[i]->disk_size;
       if (!load_file(s->opt, s->files[i])) w.failed = 1;
       i++;
     }
@@ -261,12 +364,13 @@ static int run_group(struct Slot *s, struct AADHipContext *ctx, struct File **g,
   const void **in = (const void **)malloc(sizeof(*in) * (size_t)n);
   void **out = (void **)malloc(sizeof(*out) * (size_t)n);
   uint32_t *frames = (uint32_t *)malloc(sizeof(*frames) * (size_t)n);
+  uint32_t *decoded = (uint32_t *)malloc(sizeof(*decoded) * (size_t)n);
   uint64_t *sizes = (uint64_t *)malloc(sizeof(*sizes) * (size_t)n);
   uint64_t *got = (uint64_t *)malloc(sizeof(*got) * (size_t)n);
   struct AADHipErrorStats *stats = (struct AADHipErrorStats *)malloc(sizeof(*stats) * (size_t)n);
   AADApiResult r = AAD_APIRESULT_NG;
   int k, ok = 0;
-  if (!in || !out || !frames || !sizes || !got || !stats) goto done;
+  if (!in || !out || !frames || !decoded || !sizes || !got || !stats) goto done;
 
   if (mode == 'd') {
     for (k = 0; k < n; k++) {
@@ -274,10 +378,19 @@ static int run_group(struct Slot *s, struct AADHipContext *ctx, struct File **g,
       sizes[k] = g[k]->size;
       frames[k] = g[k]->head.num_samples;
       g[k]->out_size = (uint64_t)frames[k] * g[k]->head.num_channels * 2;
-      out[k] = g[k]->out = (uint8_t *)calloc((size_t)frames[k] * g[k]->head.num_channels + 8, 2);
+      {
+        uint8_t head[AAD_WAV_HEADER_SIZE];
+        AADWav_WriteHeader(head, sizeof(head), g[k]->head.num_channels, g[k]->head.sampling_rate, frames[k]);
+        map_output(opt, g[k], ".wav", head, sizeof(head), g[k]->out_size);
+      }
+      if (g[k]->out_map == NULL) g[k]->out = (uint8_t *)malloc(((size_t)frames[k] * g[k]->head.num_channels + 8) * 2);
+      out[k] = g[k]->out;
       if (out[k] == NULL) goto done;
     }
-    r = AADHip_DecodeBatch(ctx, (uint32_t)n, (const uint8_t *const *)in, sizes, (int16_t *const *)out, frames, NULL);
+    r = AADHip_DecodeBatch(ctx, (uint32_t)n, (const uint8_t *const *)in, sizes, (int16_t *const *)out, frames, decoded);
+    for (k = 0; r == AAD_APIRESULT_OK && k < n; k++) /* an image that ends early: the frames it does not hold are silence */
+      if (decoded[k] < frames[k])
+        memset(out[k] + (size_t)decoded[k] * g[k]->head.num_channels * 2, 0, (size_t)(frames[k] - decoded[k]) * g[k]->head.num_channels * 2);
   } else {
     param.num_channels = g[0]->wav.num_channels;
     param.sampling_rate = g[0]->wav.sampling_rate;
@@ -288,8 +401,16 @@ static int run_group(struct Slot *s, struct AADHipContext *ctx, struct File **g,
       sizes[k] = mode == 'e' ? AADHip_CalculateEncodedSize(&param, frames[k]) : (uint64_t)frames[k] * param.num_channels * 2;
       out[k] = NULL;
       if (mode != 'c') {
-        out[k] = g[k]->out = (uint8_t *)malloc((size_t)sizes[k] + 16);
         g[k]->out_size = sizes[k];
+        if (mode == 'e') {
+          map_output(opt, g[k], ".aad", NULL, 0, sizes[k]);
+        } else {
+          uint8_t head[AAD_WAV_HEADER_SIZE];
+          AADWav_WriteHeader(head, sizeof(head), g[k]->wav.num_channels, g[k]->wav.sampling_rate, frames[k]);
+          map_output(opt, g[k], ".wav", head, sizeof(head), sizes[k]);
+        }
+        if (g[k]->out_map == NULL) g[k]->out = (uint8_t *)malloc((size_t)sizes[k] + 16);
+        out[k] = g[k]->out;
         if (out[k] == NULL) goto done;
       }
     }
@@ -314,6 +435,7 @@ done:
   free(in);
   free(out);
   free(frames);
+  free(decoded);
   free(sizes);
   free(got);
   free(stats);
@@ -368,7 +490,13 @@ static void *writer_main(void *arg)
     for (i = w.first; i < w.last; i++) {
       struct File *f = s->files[i];
       int wrote = 1;
-      if (!failed && f->done && opt->mode != 'c') {
+      if (f->out_map != NULL) { /* already in the file: keep it, or take it away again after a failure */
+        wrote = finish_mapped(opt, f, opt->mode == 'e' ? ".aad" : ".wav", !failed && f->done);
+        if (!wrote && !failed && f->done) {
+          fprintf(stderr, "aad_batch: cannot write output for %s\n", f->path);
+          failed = 1;
+        }
+      } else if (!failed && f->done && opt->mode != 'c') {
         if (opt->mode == 'e') {
           wrote = write_out(opt->outdir, f->path, ".aad", NULL, 0, f->out, (size_t)f->out_size);
         } else {
@@ -424,6 +552,15 @@ static int by_stem(const void *a, const void *b)
   return c != 0 ? c : (la < lb ? -1 : la > lb);
 }
 
+/* a mapped output file that cannot get its pages (device full) or a mapped input that shrank */
+static void on_sigbus(int sig)
+{
+  static const char msg[] = "aad_batch: I/O error on a mapped file (output device full, or an input changed while it was read)\n";
+  (void)sig;
+  if (write(2, msg, sizeof(msg) - 1) < 0) _exit(1);
+  _exit(1);
+}
+
 int main(int argc, char **argv)
 {
   struct Options opt;
@@ -435,6 +572,7 @@ int main(int argc, char **argv)
   struct File *files = NULL, **order = NULL;
   int i, k, npaths = 0, cap, rc = 1, started = 0;
 
+  signal(SIGBUS, on_sigbus);
   memset(&opt, 0, sizeof(opt));
   memset(slots, 0, sizeof(slots));
   opt.param.bits_per_sample = 4; /* reference defaults, src/main.c:39-50 */
@@ -475,7 +613,7 @@ int main(int argc, char **argv)
     char *p;
     memset(&lf, 0, sizeof(lf));
     lf.path = list;
-    if (!slurp(&lf)) {
+    if (!slurp_copy(&lf)) {
       fprintf(stderr, "aad_batch: cannot read list %s\n", list);
       free(lf.bytes);
       goto cleanup;
