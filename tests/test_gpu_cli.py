@@ -86,3 +86,40 @@ def test_non_16_bit_wav_input_matches_reference_cli(tmp_path):
         for k, c in members:
             aad = (out / ("case%02d.aad" % k)).read_bytes()
             assert len(aad) == c["aad_bytes"] and _sha(aad) == c["aad_sha256"], c
+
+
+def test_failed_wave_leaves_no_outputs_and_truncated_images_decode_to_silence(tmp_path):
+    """Outputs are files created up front and filled in place.  A wave whose device call fails (one image
+    ends inside a block header: the reference's INSUFFICIENT_DATA) must leave none of them behind; an
+    image that merely ends early decodes like the reference's block walk and the frames it does not hold
+    come out as silence."""
+    src, dec = tmp_path / "src", tmp_path / "dec"
+    src.mkdir()
+    dec.mkdir()
+    images = {}
+    for i in range(5):
+        pcm = synth_pcm(1, 6000 + 500 * i, 2, seed=900 + i)[0]
+        images["g%d" % i] = ob.encode(pcm, 4, 1024, 48000, False, 0)
+    bad = dict(images)
+    bad["g3"] = images["g3"][: 31 + 1024 * 2 + 10]          # inside block 2's header
+    for n, b in bad.items():
+        (src / (n + ".aad")).write_bytes(b)
+    r = subprocess.run([CLI, "-d", "-o", str(dec)] + [str(src / (n + ".aad")) for n in bad], timeout=300,
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "failed" in r.stderr
+    assert list(dec.iterdir()) == []
+    ok = dict(images)
+    ok["g3"] = images["g3"][: 31 + 1024 * 2 + 500]          # block 2 present in part: decoded as far as the walk goes
+    for n, b in ok.items():
+        (src / (n + ".aad")).write_bytes(b)
+    subprocess.run([CLI, "-d", "-o", str(dec)] + [str(src / (n + ".aad")) for n in ok], check=True, timeout=300)
+    for n, b in images.items():
+        want, hd = ob.decode(b)
+        got = read_wav16(str(dec / (n + ".wav")))[0]
+        if n != "g3":
+            assert (dec / (n + ".wav")).read_bytes() == wav16_bytes(want, 48000), n
+        else:
+            spb = 992
+            assert got.shape == want.shape
+            assert np.array_equal(got[: 3 * spb], ob.decode(ok["g3"])[0][: 3 * spb])
+            assert not got[3 * spb:].any()
