@@ -293,14 +293,27 @@ __device__ __forceinline__ int32_t predict(const Lane &L)
   return (int32_t)acc >> 15;
 }
 
-/* LMS and history update - reference src/aad_encoder.c:396-406, src/aad_decoder.c:306-315.
- * qd*h fits 32 bits (|qd| <= 61438, |h| <= 32768), so the 24-bit multiplier is exact. */
+/* LMS and history update - reference src/aad_encoder.c:396-406, src/aad_decoder.c:306-315:
+ *   w += (qd * h + 16384) >> 18.
+ * One lane holding all four taps (the dense mapping) spends three instructions per tap on that
+ * (v_mad_i32_i24, v_ashrrev_i32, v_add_u32).  With q14 = qd << 14, computed once per sample,
+ *   (qd * h + 16384) >> 18  =  high 32 bits of  q14 * h + 2^28        (64-bit, arithmetic floor)
+ * exactly - (qd * h + 16384) * 2^14 is the 64-bit sum, its upper half the same floor - so a tap is
+ * one v_mad_i64_i32 (the 2^28 sits in a scalar register pair) and one add: 9 instructions per sample
+ * instead of 12.  |qd| <= 61438 < 2^16, so q14 fits 31 bits. */
+__device__ __forceinline__ int32_t lms_q14(int32_t qd) { return (int32_t)((uint32_t)qd << 14); }
+__device__ __forceinline__ int32_t lms_tap(int32_t w, int32_t q14, int32_t h)
+{
+  const int64_t t = (int64_t)q14 * (int64_t)h + (int64_t)(1ll << 28);
+  return (int32_t)((uint32_t)w + (uint32_t)(t >> 32));
+}
 __device__ __forceinline__ void lms_and_shift(Lane &L, int32_t qd, int32_t y)
 {
-  L.w0 += mad_i24(qd, L.h0, 16384) >> 18;
-  L.w1 += mad_i24(qd, L.h1, 16384) >> 18;
-  L.w2 += mad_i24(qd, L.h2, 16384) >> 18;
-  L.w3 += mad_i24(qd, L.h3, 16384) >> 18;
+  const int32_t q14 = lms_q14(qd);
+  L.w0 = lms_tap(L.w0, q14, L.h0);
+  L.w1 = lms_tap(L.w1, q14, L.h1);
+  L.w2 = lms_tap(L.w2, q14, L.h2);
+  L.w3 = lms_tap(L.w3, q14, L.h3);
   L.h3 = L.h2;
   L.h2 = L.h1;
   L.h1 = L.h0;
@@ -310,13 +323,15 @@ __device__ __forceinline__ void lms_and_shift(Lane &L, int32_t qd, int32_t y)
 /* LMS split in two halves for the hand-pipelined encoder (taps 0-1, then taps 2-3 + shift) */
 __device__ __forceinline__ void lms_first(Lane &L, int32_t qd)
 {
-  L.w0 += mad_i24(qd, L.h0, 16384) >> 18;
-  L.w1 += mad_i24(qd, L.h1, 16384) >> 18;
+  const int32_t q14 = lms_q14(qd);
+  L.w0 = lms_tap(L.w0, q14, L.h0);
+  L.w1 = lms_tap(L.w1, q14, L.h1);
 }
 __device__ __forceinline__ void lms_rest_and_shift(Lane &L, int32_t qd, int32_t y)
 {
-  L.w2 += mad_i24(qd, L.h2, 16384) >> 18;
-  L.w3 += mad_i24(qd, L.h3, 16384) >> 18;
+  const int32_t q14 = lms_q14(qd);
+  L.w2 = lms_tap(L.w2, q14, L.h2);
+  L.w3 = lms_tap(L.w3, q14, L.h3);
   L.h3 = L.h2;
   L.h2 = L.h1;
   L.h1 = L.h0;
