@@ -39,35 +39,38 @@ __device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const ch
 {
   static_assert(N >= 2 && N <= kChunk, "the first N samples of a chunk's code words");
   constexpr int cpw = Pack<BITS>::kCodesPerWord;
-  auto code_addr = [&](int j) -> uint32_t { /* (code << kLdsCodeShift) for sample j, j compile-time after unrolling */
-    constexpr int sh = kLdsCodeShift;
+  auto code_addr = [&](int j) -> uint32_t { /* (code << 4) for sample j, j compile-time after unrolling */
+    constexpr int sh = 4;
     const int pos = Pack<BITS>::pos(j % cpw);
     const uint32_t word = w[j / cpw];
     return (pos >= sh ? word >> (pos >= sh ? pos - sh : 0) : word << (sh - pos)) & (((1u << BITS) - 1u) << sh);
   };
-  uint32_t step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
+  auto record = [&](uint32_t addr) { return *reinterpret_cast<const u32x3 *>(lds + kLdsDenseCodeOff + addr); };
+  const uint32_t copy = (threadIdx.x & 3u) << 2;
+  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsDenseStepOff + (((uint32_t)idxb & 0xFF0u) | copy)); };
+  uint32_t step = step_at(L.idxb); /* step << 2 */
   /* per-code records two samples ahead: they depend on nothing but the code bits */
-  u32x2 t0 = code_record(lds, code_addr(0));
-  u32x2 t1 = code_record(lds, code_addr(1));
+  u32x3 t0 = record(code_addr(0));
+  u32x3 t1 = record(code_addr(1));
   int32_t p = predict(L);
   static_for<0, N>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     /* A */
     const uint32_t step_j = step;
-    const u32x2 t_j = t0;
+    const u32x3 t_j = t0;
     t0 = t1;
-    L.idxb = clamp_idx(L.idxb + record_delta(t_j));
-    if (j + 1 < N) step = *reinterpret_cast<const uint32_t *>(lds + kLdsStepOff + slot_addr(L.idxb));
-    if (j + 2 < N) t1 = code_record(lds, code_addr(j + 2 < N ? j + 2 : j));
+    L.idxb = clamp_idx(L.idxb + (int32_t)(int16_t)t_j.x);
+    if (j + 1 < N) step = step_at(L.idxb);
+    if (j + 2 < N) t1 = record(code_addr(j + 2 < N ? j + 2 : j));
     __builtin_amdgcn_sched_barrier(0);
     /* B */
-    const int32_t qd = record_dequantise<BITS>(step_j, t_j);
+    const int32_t qd = dense_dequantise(step_j, t_j);
     const int32_t yy = clip16(qd + p);
-    lms_and_shift(L, qd, yy);
     if (j + 1 < N) {
-      p = predict(L);
+      p = lms_shift_predict(L, qd, yy);
       pin(p);
     } else {
+      lms_and_shift(L, qd, yy);
       pin_weights(L);
     }
     y[j] = finish(yy);
@@ -331,9 +334,10 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   static_assert(!NT || (CHF == 2 && !QUAD && BITS != 3), "streamed stores: dense stereo kernel with the 16-frame lead chunk");
-  __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytes];
+  __shared__ __attribute__((aligned(16))) char lds[QUAD ? kLdsBytesQuad : kLdsBytesDenseDec];
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, QUAD>(lds);
+  if constexpr (!QUAD) stage_dense_decode_tables<BITS>(lds);
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   const uint32_t ch = CHF ? CHF : a.channels;

@@ -111,6 +111,13 @@ __device__ __forceinline__ uint32_t wide_addr(int32_t idxb) { return (uint32_t)i
  * where the unscaled form took one v_and_b32), the deltas come scaled as well. */
 constexpr int kLdsBytesQuadEnc = kLdsWideOff + AAD_STEP_TABLE_LEN * 64;
 constexpr int kIdxScale = 4;
+/* Dense DECODER: step << 2 in four copies per 16-byte slot (copy = lane & 3 spreads a wave's lookups
+ * over all banks; the slot's address is idxb & 0xFF0, one v_and_or_b32 with the copy offset) and
+ * 16-byte per-code records {bias << 29 | delta & 0xFFFF, 0, sm21 << 27, -} for the one-instruction
+ * dequantiser (dense_dequantise). */
+constexpr int kLdsDenseStepOff = (kLdsBytes + 15) & ~15;
+constexpr int kLdsDenseCodeOff = kLdsDenseStepOff + AAD_STEP_TABLE_LEN * 16;
+constexpr int kLdsBytesDenseDec = kLdsDenseCodeOff + 16 * 16;
 constexpr int kWideStepShift = 9; /* the encoders' wide records hold step << 9: a 24-bit factor for v_mul_hi_u32_u24 */
 __device__ __forceinline__ uint32_t wide4_addr(int32_t j, uint32_t copy_off) { return ((uint32_t)j & 0x3FC0u) | copy_off; }
 
@@ -245,6 +252,44 @@ __device__ __forceinline__ void stage_tables(char *lds)
   __syncthreads();
 }
 
+/* the dense decoder's extra tables (after stage_tables, which ends in a barrier) */
+template <int BITS>
+__device__ __forceinline__ void stage_dense_decode_tables(char *lds)
+{
+  constexpr int kShift = BITS - 1;
+  const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
+  for (int i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) {
+    const uint32_t v = (uint32_t)c_step_table[i] << 2;
+    u32x4 e = {v, v, v, v};
+    *reinterpret_cast<u32x4 *>(lds + kLdsDenseStepOff + (i << 4)) = e;
+  }
+  if (threadIdx.x < (1 << BITS)) {
+    const int code = threadIdx.x, mag = code & ((1 << kShift) - 1), neg = code >> kShift;
+    const int32_t sm21 = neg ? -(2 * mag + 1) : (2 * mag + 1);
+    const uint32_t bias = neg ? (1u << kShift) - 1u : 0u;
+    u32x4 e;
+    /* (step * sm21 + bias) >> (BITS - 1) as the upper half of (step << 2) * (sm21 << 27) + (bias << 29),
+     * scaled for BITS = 4 (>> 3 = 29 - 32); fewer bits shift less: the factor moves up accordingly.
+     * Whatever sits in the low 29 bits of the addend (the index delta does) cannot carry into bit 29
+     * of a sum of multiples of 2^29 and is dropped with the lower half. */
+    e.x = (bias << (32 - kShift)) | ((uint32_t)(int32_t)dt[mag] & 0xFFFFu);
+    e.y = 0;
+    e.z = (uint32_t)sm21 << (30 - kShift);
+    e.w = 0;
+    *reinterpret_cast<u32x4 *>(lds + kLdsDenseCodeOff + (code << 4)) = e;
+  }
+  __syncthreads();
+}
+
+/* qd = (step * sm21 + bias) >> (BITS - 1), sign included, in one v_mad_i64_i32: step4 = step << 2,
+ * rec = the code's record {addend, 0, factor} */
+__device__ __forceinline__ int32_t dense_dequantise(uint32_t step4, const u32x3 &rec)
+{
+  const uint64_t addend = (uint64_t)rec.x | ((uint64_t)rec.y << 32);
+  const int64_t t = (int64_t)(int32_t)rec.z * (int64_t)(int32_t)step4 + (int64_t)addend;
+  return (int32_t)(t >> 32);
+}
+
 __device__ __forceinline__ int32_t clip16(int32_t v) { return min(max(v, -32768), 32767); }
 
 /* Pin a value's computation between the surrounding scheduling barriers.  sched_barrier only
@@ -254,6 +299,7 @@ __device__ __forceinline__ int32_t clip16(int32_t v) { return min(max(v, -32768)
 __device__ __forceinline__ void pin(int32_t &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(uint32_t &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin64(uint64_t &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ int32_t clamp_idx(int32_t v) { return min(max(v, kIdxMin), kIdxMax); }
 
 /* a*b + c on the 24-bit multiplier (v_mad_i32_i24).  Both operands MUST fit 24 signed bits; the
@@ -318,6 +364,36 @@ __device__ __forceinline__ void lms_and_shift(Lane &L, int32_t qd, int32_t y)
   L.h2 = L.h1;
   L.h1 = L.h0;
   L.h0 = y;
+}
+
+/* LMS, history shift and the NEXT sample's prediction in one: tap i of the prediction needs only the
+ * updated weight i and the shifted history, so the eight 64-bit multiply-adds alternate - no two
+ * dependent ones back to back (a dependent pair costs a wait state) */
+__device__ __forceinline__ int32_t lms_shift_predict(Lane &L, int32_t qd, int32_t y)
+{
+  const int32_t q14 = lms_q14(qd);
+  uint64_t acc = 16384u;
+  const int32_t w0 = lms_tap(L.w0, q14, L.h0);
+  acc += (uint64_t)(uint32_t)y * (uint64_t)(uint32_t)w0;
+  pin64(acc);
+  const int32_t w1 = lms_tap(L.w1, q14, L.h1);
+  acc += (uint64_t)(uint32_t)L.h0 * (uint64_t)(uint32_t)w1;
+  pin64(acc);
+  const int32_t w2 = lms_tap(L.w2, q14, L.h2);
+  acc += (uint64_t)(uint32_t)L.h1 * (uint64_t)(uint32_t)w2;
+  pin64(acc);
+  const int32_t w3 = lms_tap(L.w3, q14, L.h3);
+  acc += (uint64_t)(uint32_t)L.h2 * (uint64_t)(uint32_t)w3;
+  pin64(acc);
+  L.h3 = L.h2;
+  L.h2 = L.h1;
+  L.h1 = L.h0;
+  L.h0 = y;
+  L.w0 = w0;
+  L.w1 = w1;
+  L.w2 = w2;
+  L.w3 = w3;
+  return (int32_t)(uint32_t)acc >> 15;
 }
 
 /* LMS split in two halves for the hand-pipelined encoder (taps 0-1, then taps 2-3 + shift) */

@@ -128,7 +128,6 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     const int32_t q = (int32_t)(__umul24(step9, m21) >> (BITS - 1 + kWideStepShift)); /* (step * (2 mag + 1)) >> (BITS - 1) */
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
-    lms_first(L, qd);
     if (EMIT) {
       uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
       uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
@@ -138,22 +137,21 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     } else {
       sq += wrapped_square(qd);
     }
-    pin_weights(L);
     __builtin_amdgcn_sched_barrier(0);
     /* C */
     idxj = min(max(idxj + delta, kIdxScale * kIdxMin), kIdxScale * kIdxMax);
     if (j + 1 < kChunk) e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide4_addr(idxj, copy));
     __builtin_amdgcn_sched_barrier(0);
-    /* D */
-    lms_rest_and_shift(L, qd, y);
+    /* D: LMS, history shift and the next prediction as alternating 64-bit multiply-adds (lms_shift_predict) */
     if (j + 1 < kChunk) {
-      p = predict(L);
+      p = lms_shift_predict(L, qd, y);
       d = sample(j + 1) - p;
       m = d >> 31;
       f = (float)d;
       pin(m);
       pin(f);
     } else {
+      lms_and_shift(L, qd, y);
       qd_out = qd;
       pin_weights(L);
     }
