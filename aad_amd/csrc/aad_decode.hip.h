@@ -39,13 +39,13 @@ __device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const ch
 {
   static_assert(N >= 2 && N <= kChunk, "the first N samples of a chunk's code words");
   constexpr int cpw = Pack<BITS>::kCodesPerWord;
-  auto code_addr = [&](int j) -> uint32_t { /* (code << 4) for sample j, j compile-time after unrolling */
-    constexpr int sh = 4;
+  auto code_addr = [&](int j) -> uint32_t { /* (code << 2) for sample j, j compile-time after unrolling */
+    constexpr int sh = 2;
     const int pos = Pack<BITS>::pos(j % cpw);
     const uint32_t word = w[j / cpw];
     return (pos >= sh ? word >> (pos >= sh ? pos - sh : 0) : word << (sh - pos)) & (((1u << BITS) - 1u) << sh);
   };
-  auto record = [&](uint32_t addr) { return *reinterpret_cast<const u32x3 *>(lds + kLdsDenseCodeOff + addr); };
+  auto record = [&](uint32_t addr) { return dense_code_record(lds, addr); };
   const uint32_t copy = (threadIdx.x & 3u) << 2;
   auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsDenseStepOff + (((uint32_t)idxb & 0xFF0u) | copy)); };
   uint32_t step = step_at(L.idxb); /* step << 2 */
