@@ -111,15 +111,14 @@ __device__ __forceinline__ uint32_t wide_addr(int32_t idxb) { return (uint32_t)i
  * where the unscaled form took one v_and_b32), the deltas come scaled as well. */
 constexpr int kLdsBytesQuadEnc = kLdsWideOff + AAD_STEP_TABLE_LEN * 64;
 constexpr int kIdxScale = 4;
-/* Dense DECODER: step << 2 in four copies per 16-byte slot (copy = lane & 3 spreads a wave's lookups
- * over all banks; the slot's address is idxb & 0xFF0, one v_and_or_b32 with the copy offset) and,
+/* Dense DECODER: a dword array of step << 2 and,
  * for the one-instruction dequantiser (dense_dequantise), three 16-dword arrays indexed by the code:
  * the addend (bias << 29 | delta & 0xFFFF), sixteen zeros - read together with the addend by one
  * ds_read2_b32, they are the upper half of the 64-bit addend - and the factor (sm21 << 27).  Sixteen
  * dwords are half a row of banks: lookups of different codes never collide (16-byte records did:
  * codes c and c + 8 share their banks, 5 conflict cycles per lookup). */
 constexpr int kLdsDenseStepOff = (kLdsBytes + 127) & ~127;
-constexpr int kLdsDenseCodeOff = kLdsDenseStepOff + AAD_STEP_TABLE_LEN * 16;
+constexpr int kLdsDenseCodeOff = kLdsDenseStepOff + AAD_STEP_TABLE_LEN * 4;
 constexpr int kLdsDenseZeroOff = kLdsDenseCodeOff + 64;
 constexpr int kLdsDenseFactorOff = kLdsDenseCodeOff + 128;
 constexpr int kLdsBytesDenseDec = kLdsDenseCodeOff + 192;
@@ -264,9 +263,7 @@ __device__ __forceinline__ void stage_dense_decode_tables(char *lds)
   constexpr int kShift = BITS - 1;
   const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
   for (int i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) {
-    const uint32_t v = (uint32_t)c_step_table[i] << 2;
-    u32x4 e = {v, v, v, v};
-    *reinterpret_cast<u32x4 *>(lds + kLdsDenseStepOff + (i << 4)) = e;
+    reinterpret_cast<uint32_t *>(lds + kLdsDenseStepOff)[i] = (uint32_t)c_step_table[i] << 2;
   }
   if (threadIdx.x < (1 << BITS)) {
     const int code = threadIdx.x, mag = code & ((1 << kShift) - 1), neg = code >> kShift;
