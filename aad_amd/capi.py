@@ -177,6 +177,14 @@ def load_library(path=None, hip=True):
     if not os.path.exists(path):
         raise FileNotFoundError(
             "%s is missing - the HIP extension has not been built (run __graft_entry__.build())" % path)
+    if hip:
+        # torch ships a HIP runtime of its own.  Whichever libamdhip64 is mapped first serves both; loaded
+        # the other way round (this library first, torch later) the process ends up with two runtimes and
+        # AADHip_ContextCreate fails - so python callers that have torch get it imported here.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     _declare_legacy(lib)
     if hip:
