@@ -122,12 +122,6 @@ constexpr int kLdsDenseCodeOff = kLdsDenseStepOff + AAD_STEP_TABLE_LEN * 4;
 constexpr int kLdsDenseZeroOff = kLdsDenseCodeOff + 64;
 constexpr int kLdsDenseFactorOff = kLdsDenseCodeOff + 128;
 constexpr int kLdsBytesDenseDec = kLdsDenseCodeOff + 192;
-/* Dense ENCODER: the same three per-code arrays as the dense decoder's (addend with the index delta
- * times kIdxScale in its low half, zeros, factor), scaled for step << kWideStepShift */
-constexpr int kLdsEncCodeOff = (kLdsBytesQuadEnc + 127) & ~127;
-constexpr int kLdsEncZeroOff = kLdsEncCodeOff + 64;
-constexpr int kLdsEncFactorOff = kLdsEncCodeOff + 128;
-constexpr int kLdsBytesEnc = kLdsEncCodeOff + 192;
 constexpr int kWideStepShift = 9; /* the encoders' wide records hold step << 9: a 24-bit factor for v_mul_hi_u32_u24 */
 __device__ __forceinline__ uint32_t wide4_addr(int32_t j, uint32_t copy_off) { return ((uint32_t)j & 0x3FC0u) | copy_off; }
 
@@ -284,33 +278,6 @@ __device__ __forceinline__ void stage_dense_decode_tables(char *lds)
   }
   if (threadIdx.x < 16) reinterpret_cast<uint32_t *>(lds + kLdsDenseZeroOff)[threadIdx.x] = 0;
   __syncthreads();
-}
-
-/* the dense encoder's per-code arrays (after stage_tables, which ends in a barrier) */
-template <int BITS>
-__device__ __forceinline__ void stage_dense_encode_tables(char *lds)
-{
-  constexpr int kShift = BITS - 1;
-  const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
-  if (threadIdx.x < (1 << BITS)) {
-    const int code = threadIdx.x, mag = code & ((1 << kShift) - 1), neg = code >> kShift;
-    const int32_t sm21 = neg ? -(2 * mag + 1) : (2 * mag + 1);
-    const uint32_t bias = neg ? (1u << kShift) - 1u : 0u;
-    /* (step << 9) * (sm21 << (23 - kShift)) = step * sm21 * 2^(32 - kShift): see stage_dense_decode_tables */
-    reinterpret_cast<uint32_t *>(lds + kLdsEncCodeOff)[code] = (bias << (32 - kShift)) | ((uint32_t)(kIdxScale * (int32_t)dt[mag]) & 0xFFFFu);
-    reinterpret_cast<uint32_t *>(lds + kLdsEncFactorOff)[code] = (uint32_t)sm21 << (32 - kShift - kWideStepShift);
-  }
-  if (threadIdx.x < 16) reinterpret_cast<uint32_t *>(lds + kLdsEncZeroOff)[threadIdx.x] = 0;
-  __syncthreads();
-}
-
-__device__ __forceinline__ u32x3 dense_encode_code_record(const char *lds, uint32_t code4)
-{
-  u32x3 r;
-  r.x = *reinterpret_cast<const uint32_t *>(lds + kLdsEncCodeOff + code4);
-  r.y = *reinterpret_cast<const uint32_t *>(lds + kLdsEncZeroOff + code4);
-  r.z = *reinterpret_cast<const uint32_t *>(lds + kLdsEncFactorOff + code4);
-  return r;
 }
 
 /* the code's entries of the three arrays: {addend, 0, factor}; code4 = code << 2 */

@@ -121,18 +121,16 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     /* A */
     const uint32_t step9 = e.x; /* step << kWideStepShift (stage_tables), 24 bits at most */
     const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)), Pack<BITS>::kMagMax);
-    /* the code (sign included) looks up {addend, 0, factor}: the dequantised difference is then ONE
-     * v_mad_i64_i32 (dense_dequantise) instead of 2 mag + 1, multiply, shift, xor, subtract, and the index
-     * delta rides in the addend's low half */
-    uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
-    const u32x3 rec = dense_encode_code_record(lds, code << 2);
+    const uint32_t m21 = (mag << 1) | 1u;
+    const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDelta4Off - 1) + m21); /* 4 * delta */
     __builtin_amdgcn_sched_barrier(0);
     /* B */
-    const int32_t qd = dense_dequantise(step9, rec);
-    const int32_t delta = (int32_t)(int16_t)rec.x; /* 4 * delta */
+    const int32_t q = (int32_t)(__umul24(step9, m21) >> (BITS - 1 + kWideStepShift)); /* (step * (2 mag + 1)) >> (BITS - 1) */
+    const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
     if (EMIT) {
       uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
+      uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
       pin(code);
       acc = (acc << BITS) | code;                               /* v_lshl_or_b32 */
       pin(acc);
@@ -907,10 +905,9 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytesEnc]; /* dense and quad encoders share the four-copy wide table */
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytesQuadEnc]; /* dense and quad encoders share the four-copy wide table */
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, true, kWideStepShift, true>(lds);
-  if constexpr (!QUAD) stage_dense_encode_tables<BITS>(lds);
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   const uint32_t ch = CHF ? CHF : a.channels;
