@@ -39,17 +39,20 @@ __device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const ch
 {
   static_assert(N >= 2 && N <= kChunk, "the first N samples of a chunk's code words");
   constexpr int cpw = Pack<BITS>::kCodesPerWord;
-  auto code_addr = [&](int j) -> uint32_t { /* (code << 2) for sample j, j compile-time after unrolling */
-    constexpr int sh = 2;
+  auto code_addr = [&](int j) -> uint32_t { /* (code << 4) for sample j, j compile-time after unrolling */
+    constexpr int sh = 4;
     const int pos = Pack<BITS>::pos(j % cpw);
     const uint32_t word = w[j / cpw];
     return (pos >= sh ? word >> (pos >= sh ? pos - sh : 0) : word << (sh - pos)) & (((1u << BITS) - 1u) << sh);
   };
-  auto record = [&](uint32_t addr) { return dense_code_record(lds, addr); };
-  /* the plain dword array: its address costs two instructions (shift, mask) where a 16-byte slot would
-   * cost one, but step indices of the streams in a wave sit close together and neighbouring slots of
-   * a dword array never share a bank (16-byte slots: 2.9 conflict cycles per lookup, measured) */
-  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsDenseStepOff + slot_addr(idxb)); };
+  /* ONE lookup each for the code's record and the step, the step's address ONE instruction: measured
+   * against per-code dword arrays and a dword step array (conflict-free, but three lookups and a
+   * two-instruction address), same box, kernel time in us - 1000 x 16 blocks 66.4 vs 71.2, 1250 x 10
+   * blocks 65.2 vs 69.8, 20 000 mono blocks 121 vs 137; at saturation, where the kernel waits for
+   * memory, the same (0.60 ms) although the records cost 5 conflict cycles per lookup there */
+  auto record = [&](uint32_t addr) { return *reinterpret_cast<const u32x3 *>(lds + kLdsDenseCodeOff + addr); };
+  const uint32_t copy = (threadIdx.x & 3u) << 2;
+  auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsDenseStepOff + (((uint32_t)idxb & 0xFF0u) | copy)); };
   uint32_t step = step_at(L.idxb); /* step << 2 */
   /* per-code records two samples ahead: they depend on nothing but the code bits */
   u32x3 t0 = record(code_addr(0));
@@ -516,9 +519,9 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       }
       if (full) L.idxb = C.idx_next; /* drop the run-ahead: the tail below is not pipelined */
     } else {
-      /* Two chunks at a time: the first one's packed PCM waits in registers (eight of them) and both go
-       * out back to back - 128 contiguous bytes of a stream (mono: 64, a whole granule instead of two
-       * halves) reach the memory side together instead of a chunk's worth of time apart. */
+      /* Mono: two chunks at a time - the first one's packed PCM waits in registers (eight of them) and
+       * both go out back to back, a whole 64-byte granule instead of two halves a chunk's worth of time
+       * apart. */
       auto body = [&](uint32_t k) -> ChunkPcm {
         uint32_t w[2] = {0, 0};
         next.unpack(c, w);
@@ -533,13 +536,15 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         return pack_chunk_pcm<(CHF ? CHF : 1), false>(y, c);
       };
       uint32_t k = 0;
-      for (; k + 2 <= full; k += 2) {
+      /* stereo chunks are whole granules already and the pairing costs a latency-bound launch 2 %
+       * (1000 x 16 blocks: 71.2 -> 72.9 us) for 2.6 % at saturation: mono only */
+      for (; CHF == 1 && k + 2 <= full; k += 2) {
         const ChunkPcm a = body(k), b = body(k + 1);
         put_chunk_pcm<(CHF ? CHF : 1), NT>(op, a, c);
         put_chunk_pcm<(CHF ? CHF : 1), NT>(op + (uint64_t)kChunk * ch, b, c);
         op += (uint64_t)2 * kChunk * ch;
       }
-      if (k < full) { /* (four chunks at a time: 84 registers instead of 66, no faster - measured) */
+      for (; k < full; k++) {
         const ChunkPcm a = body(k);
         put_chunk_pcm<(CHF ? CHF : 1), NT>(op, a, c);
         op += (uint64_t)kChunk * ch;

@@ -111,17 +111,13 @@ __device__ __forceinline__ uint32_t wide_addr(int32_t idxb) { return (uint32_t)i
  * where the unscaled form took one v_and_b32), the deltas come scaled as well. */
 constexpr int kLdsBytesQuadEnc = kLdsWideOff + AAD_STEP_TABLE_LEN * 64;
 constexpr int kIdxScale = 4;
-/* Dense DECODER: a dword array of step << 2 and,
- * for the one-instruction dequantiser (dense_dequantise), three 16-dword arrays indexed by the code:
- * the addend (bias << 29 | delta & 0xFFFF), sixteen zeros - read together with the addend by one
- * ds_read2_b32, they are the upper half of the 64-bit addend - and the factor (sm21 << 27).  Sixteen
- * dwords are half a row of banks: lookups of different codes never collide (16-byte records did:
- * codes c and c + 8 share their banks, 5 conflict cycles per lookup). */
-constexpr int kLdsDenseStepOff = (kLdsBytes + 127) & ~127;
-constexpr int kLdsDenseCodeOff = kLdsDenseStepOff + AAD_STEP_TABLE_LEN * 4;
-constexpr int kLdsDenseZeroOff = kLdsDenseCodeOff + 64;
-constexpr int kLdsDenseFactorOff = kLdsDenseCodeOff + 128;
-constexpr int kLdsBytesDenseDec = kLdsDenseCodeOff + 192;
+/* Dense DECODER: step << 2 in four copies per 16-byte slot (copy = lane & 3 spreads a wave's lookups
+ * over all banks; the slot's address is idxb & 0xFF0, one v_and_or_b32 with the copy offset) and
+ * 16-byte per-code records {bias << 29 | delta & 0xFFFF, 0, sm21 << 27, -} for the one-instruction
+ * dequantiser (dense_dequantise). */
+constexpr int kLdsDenseStepOff = (kLdsBytes + 15) & ~15;
+constexpr int kLdsDenseCodeOff = kLdsDenseStepOff + AAD_STEP_TABLE_LEN * 16;
+constexpr int kLdsBytesDenseDec = kLdsDenseCodeOff + 16 * 16;
 constexpr int kWideStepShift = 9; /* the encoders' wide records hold step << 9: a 24-bit factor for v_mul_hi_u32_u24 */
 __device__ __forceinline__ uint32_t wide4_addr(int32_t j, uint32_t copy_off) { return ((uint32_t)j & 0x3FC0u) | copy_off; }
 
@@ -263,31 +259,26 @@ __device__ __forceinline__ void stage_dense_decode_tables(char *lds)
   constexpr int kShift = BITS - 1;
   const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
   for (int i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) {
-    reinterpret_cast<uint32_t *>(lds + kLdsDenseStepOff)[i] = (uint32_t)c_step_table[i] << 2;
+    const uint32_t v = (uint32_t)c_step_table[i] << 2;
+    u32x4 e = {v, v, v, v};
+    *reinterpret_cast<u32x4 *>(lds + kLdsDenseStepOff + (i << 4)) = e;
   }
   if (threadIdx.x < (1 << BITS)) {
     const int code = threadIdx.x, mag = code & ((1 << kShift) - 1), neg = code >> kShift;
     const int32_t sm21 = neg ? -(2 * mag + 1) : (2 * mag + 1);
     const uint32_t bias = neg ? (1u << kShift) - 1u : 0u;
+    u32x4 e;
     /* (step * sm21 + bias) >> (BITS - 1) as the upper half of (step << 2) * (sm21 << 27) + (bias << 29),
      * scaled for BITS = 4 (>> 3 = 29 - 32); fewer bits shift less: the factor moves up accordingly.
      * Whatever sits in the low 29 bits of the addend (the index delta does) cannot carry into bit 29
      * of a sum of multiples of 2^29 and is dropped with the lower half. */
-    reinterpret_cast<uint32_t *>(lds + kLdsDenseCodeOff)[code] = (bias << (32 - kShift)) | ((uint32_t)(int32_t)dt[mag] & 0xFFFFu);
-    reinterpret_cast<uint32_t *>(lds + kLdsDenseFactorOff)[code] = (uint32_t)sm21 << (30 - kShift);
+    e.x = (bias << (32 - kShift)) | ((uint32_t)(int32_t)dt[mag] & 0xFFFFu);
+    e.y = 0;
+    e.z = (uint32_t)sm21 << (30 - kShift);
+    e.w = 0;
+    *reinterpret_cast<u32x4 *>(lds + kLdsDenseCodeOff + (code << 4)) = e;
   }
-  if (threadIdx.x < 16) reinterpret_cast<uint32_t *>(lds + kLdsDenseZeroOff)[threadIdx.x] = 0;
   __syncthreads();
-}
-
-/* the code's entries of the three arrays: {addend, 0, factor}; code4 = code << 2 */
-__device__ __forceinline__ u32x3 dense_code_record(const char *lds, uint32_t code4)
-{
-  u32x3 r;
-  r.x = *reinterpret_cast<const uint32_t *>(lds + kLdsDenseCodeOff + code4);
-  r.y = *reinterpret_cast<const uint32_t *>(lds + kLdsDenseZeroOff + code4);
-  r.z = *reinterpret_cast<const uint32_t *>(lds + kLdsDenseFactorOff + code4);
-  return r;
 }
 
 /* qd = (step * sm21 + bias) >> (BITS - 1), sign included, in one v_mad_i64_i32: step4 = step << 2,
