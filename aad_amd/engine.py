@@ -255,13 +255,16 @@ class EncodePlan:
         self.engine, self.handle, self.param, self.descs = engine, handle, param, descs
         self.image_size = self.stride = None
 
-    def run(self, pcm, data, state=None):
-        """pcm: int16 cuda tensor, data: uint8 cuda tensor, state: int32 cuda tensor [lanes, 10] or None"""
+    def run(self, pcm, data, state=None, ordered=True):
+        """pcm: int16 cuda tensor, data: uint8 cuda tensor, state: int32 cuda tensor [lanes, 10] or None.
+        ordered=False: launch on the engine's stream without ordering it against torch's current stream
+        (the caller orders the streams itself, with events - see bench.py's pipelined step)."""
         sp = state.data_ptr() if state is not None else None
-        cur = self.engine._enter()
+        cur = self.engine._enter() if ordered else None
         _check("AADHip_EncodePlanRun",
                self.engine.lib.AADHip_EncodePlanRun(self.handle, pcm.data_ptr(), data.data_ptr(), sp))
-        self.engine._exit(cur)
+        if ordered:
+            self.engine._exit(cur)
 
     def close(self):
         if self.handle:
@@ -279,11 +282,12 @@ class DecodePlan:
     def __init__(self, engine, handle, header, descs):
         self.engine, self.handle, self.header, self.descs = engine, handle, header, descs
 
-    def run(self, data, pcm):
-        cur = self.engine._enter()
+    def run(self, data, pcm, ordered=True):
+        cur = self.engine._enter() if ordered else None
         _check("AADHip_DecodePlanRun",
                self.engine.lib.AADHip_DecodePlanRun(self.handle, data.data_ptr(), pcm.data_ptr()))
-        self.engine._exit(cur)
+        if ordered:
+            self.engine._exit(cur)
 
     def close(self):
         if self.handle:
@@ -297,6 +301,63 @@ class DecodePlan:
             pass
 
 
+class EncodeDecodePipeline:
+    """Encode on one context, decode on another: the encode of step k+1 runs while step k decodes.
+
+    On a batch that fills only part of the chip (BASELINE's 1000 one-block streams occupy 125 of 256
+    CUs with either kernel) the two kernels of consecutive steps share the device instead of taking
+    turns.  Two streams ordered by events; the .aad images go through a ring of buffers so that an
+    encode never overwrites what a decode still reads (one wait per half ring: the decode stream runs
+    in order).  Every step encodes its whole batch and decodes exactly what it encoded; `pcm` and `out`
+    are the caller's and must stay untouched until the step's kernels have run."""
+
+    def __init__(self, enc_engine, dec_engine, param, streams, samples, ring=8):
+        assert ring >= 2 and ring % 2 == 0
+        assert enc_engine.stream.cuda_stream != dec_engine.stream.cuda_stream, "the two contexts need streams of their own"
+        torch = enc_engine.torch
+        self.torch, self.ring, self.k = torch, ring, 0
+        self.enc_engine, self.dec_engine = enc_engine, dec_engine
+        self.enc = enc_engine.uniform_encode_plan(param, streams, samples)
+        self.images = [torch.zeros((streams, self.enc.stride), dtype=torch.uint8, device="cuda:%d" % enc_engine.device)
+                       for _ in range(ring)]
+        # the header comes from a first encode of silence: the decode plan needs the block geometry
+        zero = torch.zeros((streams, samples, param.num_channels), dtype=torch.int16, device=self.images[0].device)
+        self.enc.run(zero, self.images[0])
+        torch.cuda.synchronize()
+        self.header = parse_header(bytes(self.images[0][0, :31].cpu().numpy()))
+        self.dec = dec_engine.uniform_decode_plan(self.header, streams, self.enc.stride, self.enc.image_size)
+        self.encoded = [torch.cuda.Event() for _ in range(ring)]
+        self.decoded = [torch.cuda.Event() for _ in range(ring)]
+
+    def step(self, pcm, out, timing=None):
+        """timing: four timing events -> encode start / end (encode stream), decode start / end (decode stream)"""
+        k, ring = self.k, self.ring
+        self.k += 1
+        b = k % ring
+        s_enc, s_dec = self.enc_engine.stream, self.dec_engine.stream
+        if k >= ring and k % (ring // 2) == 0:  # covers the half ring of encodes that follows
+            s_enc.wait_event(self.decoded[(k - ring // 2 - 1) % ring])
+        if timing is not None:
+            timing[0].record(s_enc)
+        self.enc.run(pcm, self.images[b], None, ordered=False)
+        if timing is not None:
+            timing[1].record(s_enc)
+        self.encoded[b].record(s_enc)
+        s_dec.wait_event(self.encoded[b])
+        if timing is not None:
+            timing[2].record(s_dec)
+        self.dec.run(self.images[b], out, ordered=False)
+        if timing is not None:
+            timing[3].record(s_dec)
+        self.decoded[b].record(s_dec)
+        return self.images[b]
+
+    def close(self):
+        self.torch.cuda.synchronize()
+        self.enc.close()
+        self.dec.close()
+
+
 def parse_header(data):
     """31-byte big-endian file header (reference src/aad_decoder.c:99-170) -> AADHeaderInfo"""
     if len(data) < 31 or data[:4] != b"AAD\x00":
@@ -307,4 +368,4 @@ def parse_header(data):
                          block_size=be(24, 2), num_samples_per_block=be(26, 4), ch_process_method=data[30])
 
 
-__all__ = ["Engine", "EncodePlan", "DecodePlan", "parse_header", "make_parameter", "LANE_STATE_DTYPE"]
+__all__ = ["Engine", "EncodePlan", "DecodePlan", "EncodeDecodePipeline", "parse_header", "make_parameter", "LANE_STATE_DTYPE"]

@@ -78,33 +78,49 @@ def algorithmic_bytes_per_sample(channels, block_size, spb):
     return 2.0 + block_size / float(spb * channels)
 
 
-def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1, keep=False):
-    """-> dict with wall ms/step (max over ranks) and mean kernel durations from HIP events."""
-    from aad_amd.engine import parse_header
-    streams, samples, ch = pcm.shape
-    enc = engine.uniform_encode_plan(param, streams, samples)
-    img = torch.zeros((streams, enc.stride), dtype=torch.uint8, device=pcm.device)
-    enc.run(pcm, img, None)
-    torch.cuda.synchronize()
-    header = parse_header(bytes(img[0, :31].cpu().numpy()))
-    dec = engine.uniform_decode_plan(header, streams, enc.stride, enc.image_size)
-    out = torch.zeros((streams, samples, ch), dtype=torch.int16, device=pcm.device)
+def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1, keep=False, decode_engine=None):
+    """-> dict with wall ms/step (max over ranks) and mean kernel durations from HIP events.
 
-    def step(events=None):
-        if events is not None:
-            events[0].record()
+    decode_engine: a second context (its own stream) -> the step is PIPELINED: the encode of step k+1
+    runs while step k decodes - each of the two kernels fills half the chip's CUs on this batch - on two
+    streams ordered by events, the images double-buffered so that an encode never overwrites what a
+    decode still reads.  Every step still encodes the whole batch and decodes exactly what it encoded."""
+    from aad_amd.engine import EncodeDecodePipeline, parse_header
+    streams, samples, ch = pcm.shape
+    out = torch.zeros((streams, samples, ch), dtype=torch.int16, device=pcm.device)
+    pipe = enc = dec = None
+    if decode_engine:
+        pipe = EncodeDecodePipeline(engine, decode_engine, param, streams, samples)
+        header, image_size = pipe.header, pipe.enc.image_size
+        last = [None]
+
+        def step(events=None):
+            last[0] = pipe.step(pcm, out, events)
+    else:
+        enc = engine.uniform_encode_plan(param, streams, samples)
+        img = torch.zeros((streams, enc.stride), dtype=torch.uint8, device=pcm.device)
         enc.run(pcm, img, None)
-        if events is not None:
-            events[1].record()
-        dec.run(img, out)
-        if events is not None:
-            events[2].record()
+        torch.cuda.synchronize()
+        header, image_size = parse_header(bytes(img[0, :31].cpu().numpy())), enc.image_size
+        dec = engine.uniform_decode_plan(header, streams, enc.stride, enc.image_size)
+        last = [img]
+
+        def step(events=None):
+            if events is not None:
+                events[0].record()
+            enc.run(pcm, img, None)
+            if events is not None:
+                events[1].record()
+                events[2].record()
+            dec.run(img, out)
+            if events is not None:
+                events[3].record()
 
     for _ in range(warmup):
         step()
     # HIP events bracket the two kernels on every `event_every`-th step of the timed region (each
     # record is a packet on the stream; bracketing every step would add ~2 % to a 100 us step)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if k % event_every == 0 else None
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] if k % event_every == 0 else None
            for k in range(steps)]
     torch.cuda.synchronize()
     if world > 1:
@@ -122,14 +138,17 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
         dt = float(t.item())
     timed = [e for e in evs if e is not None]
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in timed) / len(timed)
-    dec_ms = sum(e[1].elapsed_time(e[2]) for e in timed) / len(timed)
+    dec_ms = sum(e[2].elapsed_time(e[3]) for e in timed) / len(timed)
     ok = bool((out == pcm).float().mean() > 0.0)  # touch the result so nothing is elided
-    res = dict(wall_s=dt, enc_ms=enc_ms, dec_ms=dec_ms, header=header, touched=ok, image_size=enc.image_size)
-    if keep:  # what the timed steps left in HBM, for the bit-exact flags
-        res["img"] = img[:, :enc.image_size].contiguous().cpu().numpy()
+    res = dict(wall_s=dt, enc_ms=enc_ms, dec_ms=dec_ms, header=header, touched=ok, image_size=image_size)
+    if keep:  # what the LAST timed step left in HBM, for the bit-exact flags
+        res["img"] = last[0][:, :image_size].contiguous().cpu().numpy()
         res["out"] = out.cpu().numpy()
-    enc.close()
-    dec.close()
+    if pipe:
+        pipe.close()
+    else:
+        enc.close()
+        dec.close()
     return res
 
 
@@ -468,6 +487,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip trials2 / end_to_end / configs (profiling runs)")
     ap.add_argument("--saturated-streams", type=int, default=262144)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--serial", action="store_true", help="do not overlap the encode of step k+1 with the decode of step k")
     ap.add_argument("--event-every", type=int, default=8, help="bracket the kernels with HIP events on every n-th timed step")
     args = ap.parse_args()
 
@@ -502,7 +522,13 @@ def main():
     torch.cuda.synchronize()
     # everything timed below is launched on the engine's stream, and the HIP events are recorded on it
     torch.cuda.set_stream(engine.stream)
-    m = measure(engine, torch, dist, pcm, param, args.steps, args.warmup, world, args.event_every, keep=(rank == 0))
+    # Each of the two kernels fills about half of the chip's CUs on this batch (125 workgroups), so the step
+    # is pipelined over two contexts: encode of step k+1 while step k decodes (see measure()).  --serial
+    # runs the two launches of a step strictly one after the other, as rounds 1 and 2a did; the line
+    # carries that figure too (`serial`).
+    decode_engine = None if args.serial else Engine(local, stream=torch.cuda.Stream(local))  # a stream of its own, not torch's current one
+    m = measure(engine, torch, dist, pcm, param, args.steps, args.warmup, world, args.event_every, keep=(rank == 0),
+                decode_engine=decode_engine)
     hd = m["header"]
     n_step = args.streams * samples * ch  # channel-samples per direction per rank
     value = 2.0 * n_step * world * args.steps / m["wall_s"] / 1e6
@@ -535,6 +561,9 @@ def main():
             "lanes_encode": args.streams * ch,
             "lanes_decode": args.streams * args.blocks * ch,
             "value_counts": "samples encoded + samples decoded",
+            "pipeline": ("serial: the decode of step k ends before the encode of step k+1 starts" if args.serial else
+                         "two contexts on two streams: the encode of step k+1 overlaps the decode of step k (events order "
+                         "them, images double-buffered); every step encodes the whole batch and decodes what it encoded"),
         },
         "bit_exact_vs_reference_golden": golden_check(m, args.streams, samples, ch, bits, args.trials) if rank == 0 else None,
         "encode_msps": round(n_step * world / (m["enc_ms"] * 1e-3) / 1e6, 3),
@@ -553,11 +582,19 @@ def main():
         },
     }
 
+    if not args.serial:  # the same K steps with nothing overlapped, for reference
+        ks = max(10, args.steps // 4)
+        ms_ = measure(engine, torch, dist, pcm, param, ks, min(args.warmup, 3), world, args.event_every)
+        line["serial"] = {"value": round(2.0 * n_step * world * ks / ms_["wall_s"] / 1e6, 3), "unit": "Msamples/s",
+                          "steps": ks, "ms_per_step": round(ms_["wall_s"] / ks * 1e3, 5),
+                          "encode_kernel_ms": round(ms_["enc_ms"], 5), "decode_kernel_ms": round(ms_["dec_ms"], 5),
+                          "note": "one context, the decode of step k ends before the encode of step k+1 starts"}
+
     extras = world == 1 and rank == 0 and not args.no_extras
     if extras:
         # the reference CLI's default operating point: the same batch with the trial search (src/main.c:45-47)
         p2 = make_parameter(ch, bits, mbs, 48000, False, 2)
-        m2 = measure(engine, torch, dist, pcm, p2, max(10, args.steps // 4), 3, 1, 1, keep=True)
+        m2 = measure(engine, torch, dist, pcm, p2, max(10, args.steps // 4), 3, 1, 1, keep=True, decode_engine=decode_engine)
         e2 = n_step * bps / (m2["enc_ms"] * 1e-3) / 1e9
         line["trials2"] = {
             "workload": "the headline batch with num_encode_trials = 2 (reference CLI default, src/main.c:45-47)",

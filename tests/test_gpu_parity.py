@@ -600,3 +600,36 @@ def test_inconsistent_header_geometry(engine, mapping):
             continue
         got = engine.decode_host([bytes(img)])[0]
         assert np.array_equal(got, want), (spb, n)
+
+
+def test_encode_decode_pipeline_keeps_steps_apart(engine):
+    """EncodeDecodePipeline overlaps the encode of step k+1 with the decode of step k on two contexts
+    (what bench.py times).  Forty steps - five times round its ring of image buffers - with a different
+    batch every step: every step's images and decoded PCM must be the oracle's for THAT step's input,
+    whatever ran concurrently."""
+    import torch
+    from aad_amd.engine import Engine, EncodeDecodePipeline
+    second = Engine(0, stream=torch.cuda.Stream(0))
+    try:
+        streams, samples, steps = 48, 1500, 40
+        param = make_parameter(2, 4, 1024, 48000, False, 0)
+        pipe = EncodeDecodePipeline(engine, second, param, streams, samples)
+        batches = [synth_pcm(streams, samples, 2, seed=7000 + i, kind=("music", "noise", "nyquist")[i % 3]) for i in range(5)]
+        d_in = [torch.from_numpy(b).cuda() for b in batches]
+        d_out = [torch.zeros_like(d_in[0]) for _ in range(steps)]
+        for k in range(steps):
+            pipe.step(d_in[k % 5], d_out[k])
+        torch.cuda.synchronize()
+        want_img = [[ob.encode(b[s], 4, 1024) for s in range(streams)] for b in batches]
+        want_pcm = [[ob.decode(w)[0] for w in ws] for ws in want_img]
+        for k in range(steps):
+            got = d_out[k].cpu().numpy()
+            for s in range(0, streams, 5):
+                assert np.array_equal(got[s], want_pcm[k % 5][s]), (k, s)
+        for k in range(steps - 8, steps):  # the ring still holds the images of the last eight steps
+            img = pipe.images[k % 8].cpu().numpy()
+            for s in range(0, streams, 7):
+                assert bytes(img[s, :pipe.enc.image_size]) == want_img[k % 5][s], (k, s)
+        pipe.close()
+    finally:
+        second.close()
