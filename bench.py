@@ -90,7 +90,7 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
     out = torch.zeros((streams, samples, ch), dtype=torch.int16, device=pcm.device)
     pipe = enc = dec = None
     if decode_engine:
-        pipe = EncodeDecodePipeline(engine, decode_engine, param, streams, samples)
+        pipe = EncodeDecodePipeline(engine, decode_engine, param, streams, samples, ring=32)  # one cross-stream wait per 16 encodes
         header, image_size = pipe.header, pipe.enc.image_size
         last = [None]
 
