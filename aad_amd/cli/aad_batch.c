@@ -66,6 +66,7 @@ struct File {
   uint8_t *bytes;             /* file image: the file itself, mapped read-only (no copy: the library stages straight from the page cache) */
   uint64_t size;
   int mapped;                 /* bytes came from mmap */
+  uint64_t in_dev, in_ino;    /* the input file's identity: an output that would land on it is not mapped over it */
   int16_t *converted;         /* int16 PCM made from 8/24/32-bit input, else NULL */
   struct AADWavInfo wav;      /* WAV-input modes */
   struct AADHeaderInfo head;  /* decode */
@@ -171,6 +172,8 @@ static int slurp(struct File *f)
     return 0;
   }
   f->size = (uint64_t)st.st_size;
+  f->in_dev = (uint64_t)st.st_dev;
+  f->in_ino = (uint64_t)st.st_ino;
   f->mapped = 0;
   if (f->size == 0) { /* nothing to map; the parsers refuse it */
     close(fd);
@@ -233,8 +236,12 @@ static void map_output(const struct Options *opt, struct File *f, const char *ex
   char path[4096];
   int fd;
   void *m;
+  struct stat st;
   f->out_map = NULL;
   if (head_size + body_size == 0 || !out_path(path, sizeof(path), opt->outdir, f->path, ext)) return;
+  /* `-r -o .` on ./x.wav: the output IS the (mapped) input.  Truncating it now would pull the pages from
+   * under the device stage; the buffered path writes it after the input has been consumed, as before. */
+  if (stat(path, &st) == 0 && (uint64_t)st.st_dev == f->in_dev && (uint64_t)st.st_ino == f->in_ino) return;
   fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0666);
   if (fd < 0) return;
   if (ftruncate(fd, (off_t)(head_size + body_size)) != 0) {

@@ -123,3 +123,22 @@ def test_failed_wave_leaves_no_outputs_and_truncated_images_decode_to_silence(tm
             assert got.shape == want.shape
             assert np.array_equal(got[: 3 * spb], ob.decode(ok["g3"])[0][: 3 * spb])
             assert not got[3 * spb:].any()
+
+
+def test_reconstruct_in_place_over_the_input(tmp_path):
+    """`-r -o DIR` with DIR the input's own directory: the output name is the input file.  Inputs are
+    mapped files, so the output must not be created over one while it is still being read: the result is
+    the reconstruction, byte for byte what `-r` into another directory gives."""
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    b.mkdir()
+    pcm = synth_pcm(1, 40000, 2, seed=321)[0]
+    (a / "x.wav").write_bytes(wav16_bytes(pcm, 48000))
+    (b / "x.wav").write_bytes(wav16_bytes(pcm, 48000))
+    subprocess.run([CLI, "-r", "-o", str(a), str(a / "x.wav")], check=True, timeout=300)
+    other = tmp_path / "c"
+    other.mkdir()
+    subprocess.run([CLI, "-r", "-o", str(other), str(b / "x.wav")], check=True, timeout=300)
+    rec, _ = ob.decode(ob.encode(pcm, 4, 1024, 48000, False, 2))
+    assert (other / "x.wav").read_bytes() == wav16_bytes(rec, 48000)
+    assert (a / "x.wav").read_bytes() == (other / "x.wav").read_bytes()
