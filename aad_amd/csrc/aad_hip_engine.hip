@@ -209,8 +209,14 @@ struct MappingLimits {
 
 MappingLimits mapping_limits(uint32_t bits, uint32_t channels)
 {
-  MappingLimits m = {16384u, 12288u, 16384u};
-  if (bits == 3 && channels == 2) m.decode_split = 8192u;
+  /* tools/mapping_crossover.py, profiles/r02_mapping_crossover.jsonl.  Since the dense decoder's sample
+   * went from 32.5 to 24 instructions it is as fast as the fused quad decoder at every batch size
+   * (59-60 us on one-block stereo 4-bit streams, 250 to 48 000 recurrences; fused 61-67 us up to 16 384):
+   * "auto" no longer picks the fused kernel (its range is empty), the option still forces it. */
+  MappingLimits m = {16384u, 12288u, 0u};
+  if (channels == 2 && bits == 4) m.decode_split = 9216u; /* 8 000: 51.6 vs 60.1 us, 10 000: 60.5 vs 60.0 us */
+  if (channels == 2 && bits == 3) m.decode_split = 8192u; /* 8 000: 71.8 vs 79.8 us, 10 000: 88.3 vs 80.3 us */
+  m.decode_fused = m.decode_split;
   return m;
 }
 
@@ -332,7 +338,10 @@ void launch_decode(const AADHipContext *ctx, const aad::DecodeArgs &a, int32_t *
   const hipStream_t stream = ctx->stream;
   if (residual != nullptr && aad::launch_decode_split(a, residual, residual_stride, stream)) return;
   const uint64_t lanes = a.total_blocks * a.channels;
-  const bool quad = pick_decode_mapping(ctx, lanes, a.channels, BITS) != DecodeMapping::Dense;
+  /* a split decode that could not have its scratch buffer: the fused kernel when the quad mapping is
+   * forced, the dense one otherwise */
+  const DecodeMapping pick = pick_decode_mapping(ctx, lanes, a.channels, BITS);
+  const bool quad = pick == DecodeMapping::QuadFused || (pick == DecodeMapping::QuadSplit && ctx->lane_mapping == AAD_HIP_LANE_MAPPING_QUAD);
   const uint64_t threads = quad ? lanes * 4 : lanes;
   const unsigned wg = pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
