@@ -6,6 +6,8 @@ import ctypes as C
 import hashlib
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -14,7 +16,7 @@ import aad_amd
 import oracle_binding as ob
 from aad_amd.capi import LANE_STATE_DTYPE, make_parameter
 from aad_amd.synth import synth_pcm
-from helpers import GOLDEN, read_wav16, sha256, wav16_bytes
+from helpers import GOLDEN, ROOT as ROOT_DIR, read_wav16, sha256, wav16_bytes
 
 pytestmark = pytest.mark.gpu
 FIX = os.path.join(GOLDEN, "ref_fixtures")
@@ -634,3 +636,31 @@ def test_encode_decode_pipeline_keeps_steps_apart(engine):
         pipe.close()
     finally:
         second.close()
+
+
+def test_legacy_whole_file_calls_through_tiles(tmp_path):
+    """AADEncoder_EncodeWhole / AADDecoder_DecodeWhole on a 120-block stereo file with the host-memory path
+    forced into 64 KiB tiles (AAD_HIP_TILE_KBYTES, read when the handle's context is created - hence a
+    process of its own): planar int32 rows sliced by block range, the trial search's look-back block
+    carried as lead frames, M/S, the handle's state - the image and the PCM must be the oracle's."""
+    script = tmp_path / "legacy_tiles.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import torch  # noqa: F401
+import aad_amd, oracle_binding as ob
+from aad_amd.capi import LegacyCodec
+from aad_amd.synth import synth_pcm
+legacy = LegacyCodec(aad_amd.load_library())
+for ch, bits, ms, trials in ((2, 4, True, 2), (1, 3, False, 1), (2, 2, False, 0)):
+    spb = ob.geometry(1024, ch, bits)[2]
+    pcm = synth_pcm(1, 120 * spb + 77, ch, seed=31 + bits)[0]
+    img = legacy.encode(pcm, bits, 1024, 48000, ms, trials)
+    assert img == ob.encode(pcm, bits, 1024, 48000, ms, trials), (ch, bits, ms, trials)
+    assert np.array_equal(legacy.decode(img)[0], ob.decode(img)[0]), (ch, bits, ms, trials)
+print("ok")
+''' % (ROOT_DIR, os.path.join(ROOT_DIR, "tests")))
+    env = dict(os.environ, AAD_HIP_TILE_KBYTES="64")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
