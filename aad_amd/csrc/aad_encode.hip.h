@@ -206,10 +206,17 @@ struct NoFill {
  * instruction there replaces the s_nop the gap is otherwise padded with - the caller hands in the
  * chunk-level work (loads of a later chunk, the stores of the previous one, pointer arithmetic) one
  * instruction at a time, see run_block */
-template <int BITS, bool EMIT, int FORMAT = kWide, typename Fill = NoFill>
+/* PASS: what a pass over a block leaves behind - the packed codes (kPassEncode), the sum of the wrapped
+ * squares of the dequantised differences (kPassRmse: the trial search's measurement, same recurrence, no
+ * output), or both at once (kPassBoth: the dual trial search runs measurement and encode passes of
+ * different candidates side by side on different lanes of one wave - one instruction stream) */
+enum { kPassRmse = 0, kPassEncode = 1, kPassBoth = 2 };
+
+template <int BITS, int PASS, int FORMAT = kWide, typename Fill = NoFill>
 __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C, const int32_t *x, int32_t xn0,
                                                     const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq, Fill fill = Fill())
 {
+  constexpr bool EMIT = PASS != kPassRmse, SUM = PASS != kPassEncode;
   auto sample = [&](int k) -> int32_t { /* sample k of this chunk (k = 16: first of the next), k compile-time */
     if (FORMAT == kPairs) {
       const int32_t word = k < kChunk ? x[k >> 1] : xn0;
@@ -248,7 +255,8 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     if (EMIT) {
       code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
       pin(code);
-    } else {
+    }
+    if (SUM) {
       sqw = (uint32_t)qd * (uint32_t)qd;
       pin(sqw);
     }
@@ -259,9 +267,8 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
       uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
       acc = (acc << BITS) | code; /* v_lshl_or_b32 */
       pin(acc);
-    } else {
-      sq += (int64_t)(int32_t)sqw;
     }
+    if (SUM) sq += (int64_t)(int32_t)sqw;
     /* The wait for the step record asked for in A goes HERE.  It has to be somewhere before the next
      * sample's quantiser, and in this slot it doubles as the second wait state the DPP add below
      * needs (where the compiler put it, in front of the quantiser, it cost a slot of its own and
@@ -310,6 +317,9 @@ struct EncodeArgs {
    * (reference src/aad_encoder.c:503-512), so a stream continued from carried state has to bring
    * that block along. */
   uint32_t lead_frames;
+  /* dual trial search (encode_block_dual): three block-sized slots per stream, device memory of the context */
+  uint8_t *trial_scratch;
+  uint32_t trial_slot_bytes;
   UniformLayout uni;
   alignas(4) uint8_t header_template[32]; /* 31-byte file header with num_samples = 0 */
 };
@@ -494,11 +504,17 @@ constexpr bool kBurstStores = EMIT && CHF == 2 && BITS == 4;
  * the reference's running double).  Full 16-sample chunks go through the hand-pipelined bodies
  * with wide prefetched loads, the rest through encode_step.
  */
-template <int BITS, int CHF, bool MS, bool QUAD, bool EMIT, typename S>
+/* PASS (kPassRmse / kPassEncode / kPassBoth): see encode_chunk16_quad.  kPassBoth exists for the quad
+ * mapping only; `pad` then says per lane whether the pass ends like an encode pass (zero padding up to
+ * the last whole unit) or like a measurement (at the last real sample) - the sum covers real samples
+ * either way. */
+template <int BITS, int CHF, bool MS, bool QUAD, int PASS, typename S>
 __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t ch,
                                              uint32_t c, bool writer, uint8_t *body, const char *lds, int32_t &last_qd,
-                                             bool defer3 = false, uint32_t deferred = 0)
+                                             bool defer3 = false, uint32_t deferred = 0, bool pad = true)
 {
+  constexpr bool EMIT = PASS != kPassRmse;
+  static_assert(PASS != kPassBoth || QUAD, "measurement and encode in one pass: quad mapping only");
   constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
   const uint32_t unit_stride = UB * ch;
   const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
@@ -606,7 +622,7 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
             }
           }
         };
-        encode_chunk16_quad<BITS, EMIT, FMT>(L, C, reinterpret_cast<const int32_t *>(cur.d), (int32_t)ahead.d[0], lds, w, last_qd, sq, fill);
+        encode_chunk16_quad<BITS, PASS, FMT>(L, C, reinterpret_cast<const int32_t *>(cur.d), (int32_t)ahead.d[0], lds, w, last_qd, sq, fill);
         if constexpr (kStaged) {
           wp0 = w[0];
           wp1 = w[1];
@@ -653,7 +669,7 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         if (k + 2 < full) xp += (uint64_t)kChunk * ch; /* prefetch chunk k+2 (clamped to the last full one) */
         next.load(xp, ch, c);
         uint32_t w[2] = {0, 0};
-        encode_chunk16_quad<BITS, EMIT, kWide>(L, C, cur, ahead[0], lds, w, last_qd, sq);
+        encode_chunk16_quad<BITS, PASS, kWide>(L, C, cur, ahead[0], lds, w, last_qd, sq);
         next.touch();
         extract(cur);
         if (EMIT && writer) store_chunk_codes<BITS, (CHF ? CHF : 1), QUAD && !kEncTM>(body + (uint64_t)k * kOutStride * ch, w, c);
@@ -778,6 +794,29 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
     if (burst_rest >= 1) put(burst_gp + 16 * (burst_rest - 1), burst_r2);
     uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
     for (uint32_t u = 0; u < units; u++, up += unit_stride, tail >>= 8) up[0] = (uint8_t)tail;
+  } else if constexpr (PASS == kPassBoth) {
+    /* both at once: lanes that measure stop at the last real sample, lanes that encode pad the last unit
+     * with zero samples (the four taps of a recurrence agree, so the DPP traffic of a step stays whole) */
+    uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
+    for (uint32_t i = done; i < coded; i += US, up += unit_stride) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < US; k++) {
+        const bool real = i + k < coded;
+        uint32_t code = 0;
+        if (real || pad) {
+          int32_t qd;
+          code = encode_step<BITS>(L, real ? src.at(first + kTaps + i + k) : 0, lds, qd);
+          last_qd = qd;
+          if (real) sq += wrapped_square(qd);
+        }
+        acc = (acc << BITS) | code;
+      }
+      if (writer) {
+#pragma unroll
+        for (int k = 0; k < UB; k++) up[k] = (uint8_t)(acc >> (8 * (UB - 1 - k)));
+      }
+    }
   } else if (EMIT) { /* tail units: samples past n are zero padding - reference :592-593 */
     uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
     for (uint32_t i = done; i < coded; i += US, up += unit_stride) {
@@ -848,52 +887,179 @@ __device__ __forceinline__ void search_best_lane(S &L, const SampleSource<MS> &s
 }
 
 /*
- * The same search with its two independent strands on different lanes ("dual" mapping, used
- * with the quad mapping, i.e. when lanes are idle anyway).  The reference evaluates
- *   probe:  RMSE of the current block from the carried state                      (1 pass)
- *   chain:  trials x ([previous block] + current block), each from where the last ended
- * one after the other: 2 + 2t passes per block with the final encode.  The probe does not feed
- * the chain, so a second group of four lanes (role 1) runs it while role 0 runs the chain's
- * first pass; after that pass role 1 copies role 0's state and shadows it (idle lanes cost
- * nothing, switched-off lanes made the wave slower), the winner is picked exactly as the
- * reference does (strict >, probe first), and both encode - role 0 alone stores: 1 + 2t passes
- * of latency.  One call site for every pass keeps the pipelined chunk bodies in the kernel once.
+ * Trial search AND encode of one block on the "dual" mapping (quad mapping with a second group of four
+ * lanes per channel, used when lanes are idle anyway) - reference src/aad_encoder.c:470-562, 565-727.
+ * The reference evaluates, per channel and block,
+ *   probe:  RMSE of the current block from the carried state S                       (1 pass)
+ *   chain:  trials x ([previous block] + current block), each from where the last ended;
+ *           the state C_i in front of the i-th pass over the current block is candidate i
+ * one after the other, then encodes the block from the best of {S, C_1 .. C_t}: 2 + 2t passes of
+ * latency (1 + t for a first block, where probe and first trial coincide).  An encode pass is the same
+ * recurrence as a measuring pass, but from the candidate with its weights cut to what the 16-bit header
+ * fields carry (write_block_header) and with zero padding at the end - so it cannot be taken from the
+ * measurement, yet it needs nothing but the candidate: it can run BESIDE the chain instead of behind it.
+ *   role 0 runs the chain (measuring passes);
+ *   role 1 runs the probe, then encodes S and every candidate as soon as it exists - C_t while role 0
+ *          is still measuring it - each into a place no channel of the stream currently has its best
+ *          encode in: the image or one of two scratch slots (the channels of a stream share their
+ *          interleaved bytes, so a place is per stream, while the winner is per channel);
+ * every pass is ONE call of the both-at-once pass (kPassBoth), the roles differ in state, window and
+ * pointers only.  When the chain ends, so has every encode: 2t passes (3 for t = 1; t for a first block),
+ * then the winners' bytes are moved from their slots into the image, channel by channel (12-byte
+ * pieces under byte masks), which costs a few microseconds per block.  The winner is picked exactly as
+ * the reference does (strict >, probe first, trials in order).
  */
-template <int BITS, int CHF, bool MS, typename S>
-__device__ __forceinline__ void search_best_lane_dual(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t spb,
-                                                      uint32_t trials, uint32_t ch, uint32_t c, uint32_t tap, uint32_t role,
-                                                      const char *lds)
+template <int CHF>
+__device__ __forceinline__ uint32_t role_swap(uint32_t v)
+{ /* the same tap of the same channel in the other role: CHF lanes away inside an aligned group of four */
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CHF == 2 ? 0x4E /* quad_perm [2,3,0,1] */ : 0xB1 /* [1,0,3,2] */, 0xF, 0xF, false);
+}
+template <int CHF>
+__device__ __forceinline__ double role_swap_f64(double v)
 {
-  const bool have_prev = first >= spb;
+  const uint64_t u = (uint64_t)__double_as_longlong(v);
+  const uint64_t r = ((uint64_t)role_swap<CHF>((uint32_t)(u >> 32)) << 32) | role_swap<CHF>((uint32_t)u);
+  return __longlong_as_double((long long)r);
+}
+
+template <int BITS, int CHF, bool MS>
+__device__ __forceinline__ void encode_block_dual(Lane &F, int32_t &last_qd, const SampleSource<MS> &src, uint64_t first, uint32_t n,
+                                                  uint32_t spb, uint32_t trials, uint32_t c, uint32_t tap, uint32_t role,
+                                                  uint8_t *img, uint8_t *slots, uint32_t slot_bytes, const char *lds)
+{
+  static_assert(kEncTM && (CHF == 1 || CHF == 2), "tap-major quads, mono or stereo");
+  constexpr uint32_t ch = CHF;
+  constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
+  enum { kLocImage = 0, kLocA = 1, kLocB = 2, kLocNone = 3 };
+  uint8_t *const slot_a = slots, *const slot_b = slots + slot_bytes, *const slot_t = slots + 2u * (uint64_t)slot_bytes;
+  auto place = [&](uint32_t loc) -> uint8_t * { return loc == kLocImage ? img : (loc == kLocA ? slot_a : slot_b); };
+  const bool have_prev = first >= spb; /* the same for every lane of the launch */
   const uint32_t chain_passes = trials * (have_prev ? 2u : 1u);
-  constexpr uint32_t kRoleStride = (kEncTM ? 1u : 4u) * (CHF ? CHF : 1); /* lanes between the two roles' quads of a channel */
-  const int chain_lane = (int)((threadIdx.x & 63u) - role * kRoleStride); /* role 0's lane of the same tap */
-  S best = L, run = L;
-  double best_rmse = 0.0;
-  for (uint32_t p = 0; p < chain_passes; p++) {
-    /* pass 0: role 0 starts the chain, role 1 runs the probe.  From pass 1 on role 1 simply
-     * MIRRORS role 0 - same state, same window, same result: a wave with half of its lanes
-     * switched off ran these passes ~10 % slower than with all of them doing (redundant) work. */
+  const uint32_t passes = have_prev && chain_passes < 3u ? 3u : chain_passes; /* probe, S, C_1 need three turns of role 1 */
+
+  QuadLane run = to_quad(F, tap); /* the chain's state; every lane of both roles keeps the same books */
+  QuadLane held = run;            /* with a previous block: S for pass 1, C_1 for pass 2 */
+  QuadLane best_end = run;
+  int32_t best_qd = last_qd;
+  double best_rmse = 0.0, held_rmse = 0.0;
+  uint32_t best_loc = kLocNone;
+
+  for (uint32_t p = 0; p < passes; p++) {
+    /* ---- this lane's part in pass p */
+    const bool chain_active = p < chain_passes;
     const bool chain_on_prev = have_prev && (p & 1u) == 0;
-    const bool on_prev = chain_on_prev && !(p == 0 && role != 0);
-    const S before = run;
-    double r = rmse_pass<BITS, CHF, MS, true>(run, src, on_prev ? first - spb : first, on_prev ? spb : n, ch, c, tap, lds);
-    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
-    if (p == 0) {
-      /* the probe's figure goes to both roles; role 1 takes over role 0's chain state and result */
-      const double probe = __shfl(r, chain_lane + (int)kRoleStride, 64);
-      best_rmse = role == 0 ? probe : r;
-      r = __shfl(r, chain_lane, 64);
-      run.w = __shfl(run.w, chain_lane, 64);
-      run.h = __shfl(run.h, chain_lane, 64);
-      run.idxb = __shfl(run.idxb, chain_lane, 64);
+    const bool enc_pass = !have_prev || p == 1 || p == 2 || (p >= 3 && (p & 1u)); /* role 1 encodes (else: probe / nothing due) */
+    QuadLane from1 = run;
+    if (have_prev && p == 1) {
+      from1 = held; /* S; C_1 - the chain's state now - waits for pass 2 */
+      held = run;
+    } else if (have_prev && p == 2) {
+      from1 = held;
     }
-    if (!chain_on_prev && best_rmse > r) {
-      best_rmse = r;
-      best = before; /* in pass 0 both roles started from L, so `before` is the chain's as well */
+    const bool enc = role != 0 && enc_pass;
+    const bool on_prev = role == 0 && chain_on_prev && chain_active;
+    /* a place no channel of the stream has its best encode in (the same answer on both channels' lanes) */
+    const uint32_t other_loc = CHF == 2 ? pair_swap<false>(best_loc, c) : best_loc;
+    uint32_t target = kLocImage;
+    if (best_loc == kLocImage || other_loc == kLocImage) target = (best_loc == kLocA || other_loc == kLocA) ? kLocB : kLocA;
+    uint8_t *const base = enc ? place(target) : slot_t;
+    const uint64_t wfirst = on_prev ? first - spb : first;
+    const uint32_t wn = on_prev ? spb : n;
+
+    QuadLane Q = role != 0 ? from1 : run;
+    Lane Ff = from_quad<kEncTM>(Q);
+    seed_history(Ff, src, wfirst, wn);
+    Lane Fm = Ff;
+    write_block_header(Fm, base + (uint64_t)c * kBlockHeaderBytesPerCh, enc && tap == 0);
+    if (enc) Ff = Fm; /* an encode starts from the weights the header carries */
+    Q = to_quad(Ff, tap);
+    int32_t qd = last_qd;
+    const int64_t sum = run_block<BITS, CHF, MS, true, kPassBoth>(Q, src, wfirst, wn, ch, c, tap == 0,
+                                                                  base + (uint64_t)kBlockHeaderBytesPerCh * ch, lds, qd, false, 0, enc);
+    const double r = wn < (uint32_t)kTaps ? 0.0 : sqrt((double)sum / (double)wn);
+    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+
+    /* ---- both roles' results to every lane */
+    const uint32_t ow = role_swap<CHF>((uint32_t)Q.w), oh = role_swap<CHF>((uint32_t)Q.h), oi = role_swap<CHF>((uint32_t)Q.idxb);
+    const uint32_t oq = role_swap<CHF>((uint32_t)qd);
+    const double orr = role_swap_f64<CHF>(r);
+    const double r_chain = role != 0 ? orr : r, r_probe = role != 0 ? r : orr;
+    QuadLane enc_end = Q;
+    enc_end.w = role != 0 ? Q.w : (int32_t)ow;
+    enc_end.h = role != 0 ? Q.h : (int32_t)oh;
+    enc_end.idxb = role != 0 ? Q.idxb : (int32_t)oi;
+    const int32_t enc_qd = role != 0 ? qd : (int32_t)oq;
+    if (chain_active) {
+      run.w = role != 0 ? (int32_t)ow : Q.w;
+      run.h = role != 0 ? (int32_t)oh : Q.h;
+      run.idxb = role != 0 ? (int32_t)oi : Q.idxb;
+    }
+
+    /* ---- the books: strict >, probe first, trials in order (reference :520-552) */
+    bool take = false;
+    if (!have_prev) { /* pass p measured candidate p + 1 and encoded it; the first one doubles as the probe */
+      take = p == 0 || best_rmse > r_chain;
+      if (take) best_rmse = r_chain;
+    } else if (p == 0) {
+      best_rmse = r_probe;
+    } else if (p == 1) { /* S is encoded (the image); C_1 is measured, its encode comes next */
+      take = true;
+      held_rmse = r_chain;
+    } else if (p == 2) {
+      take = best_rmse > held_rmse;
+      if (take) best_rmse = held_rmse;
+    } else if (p & 1u) { /* measured and encoded in this pass */
+      take = best_rmse > r_chain;
+      if (take) best_rmse = r_chain;
+    }
+    if (take) {
+      best_loc = target;
+      best_end.w = enc_end.w;
+      best_end.h = enc_end.h;
+      best_end.idxb = enc_end.idxb;
+      best_qd = enc_qd;
     }
   }
-  L = best;
+
+  /* ---- winners that are not in the image move there, channel by channel */
+  /* the passes' stores, made by other lanes of this wave, are read below: wave (workgroup) scope is
+   * enough - an agent-scope fence writes the L2 back, ~55 us per block on a 1000-stream batch */
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  const uint32_t other_loc = CHF == 2 ? pair_swap<false>(best_loc, c) : best_loc;
+  const uint32_t loc0 = c == 0 ? best_loc : other_loc, loc1 = c == 0 ? other_loc : best_loc;
+  if (loc0 != kLocImage || loc1 != kLocImage) {
+    constexpr uint32_t kQ = 2u * CHF, kGroup = 4u * kQ; /* quads and lanes of one stream */
+    const uint32_t id = tap * kQ + (threadIdx.x & (kQ - 1u));
+    const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
+    const uint32_t used = (kBlockHeaderBytesPerCh + (coded + US - 1) / US * UB) * ch;
+    const uint8_t *const s0 = place(loc0), *const s1 = place(loc1);
+    const uint32_t pieces = used / 12u;
+    for (uint32_t q = id; q < pieces; q += kGroup) {
+      const u32x3 v0 = reinterpret_cast<const U32x3 *>(s0 + 12u * q)->v;
+      u32x3 out = v0;
+      if (CHF == 2) {
+        const u32x3 v1 = reinterpret_cast<const U32x3 *>(s1 + 12u * q)->v;
+        /* channel 0's bytes of the piece: 36 header bytes = pieces 0-2 (18 per channel), then whole
+         * units alternate (1 byte, or 3 for 3-bit codes: a 6-byte pattern, twice per piece) */
+        u32x3 m;
+        if (q == 0) m = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        else if (q == 1) m = u32x3{0xFFFFFFFFu, 0x0000FFFFu, 0u};
+        else if (q == 2) m = u32x3{0u, 0u, 0u};
+        else if (UB == 1) m = u32x3{0x00FF00FFu, 0x00FF00FFu, 0x00FF00FFu};
+        else m = u32x3{0x00FFFFFFu, 0xFFFF0000u, 0x000000FFu};
+        out.x = (v0.x & m.x) | (v1.x & ~m.x);
+        out.y = (v0.y & m.y) | (v1.y & ~m.y);
+        out.z = (v0.z & m.z) | (v1.z & ~m.z);
+      }
+      reinterpret_cast<U32x3 *>(img + 12u * q)->v = out;
+    }
+    for (uint32_t o = pieces * 12u + id; o < used; o += kGroup) { /* at most 11 bytes, all of them code bytes for stereo */
+      const uint32_t owner = CHF == 2 ? ((o - kBlockHeaderBytesPerCh * ch) / UB) & 1u : 0u;
+      img[o] = (owner ? s1 : s0)[o];
+    }
+  }
+  F = from_quad<kEncTM>(best_end);
+  last_qd = best_qd;
 }
 
 /*
@@ -962,11 +1128,14 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
     const uint32_t n = total - first < spb ? (uint32_t)(total - first) : spb;
     S L;
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
+    if constexpr (DUAL) { /* search and encode side by side, see encode_block_dual */
+      encode_block_dual<BITS, CHF, MS>(F, last_qd, src, first, n, spb, a.trials, c, tap, role, out + block_off,
+                                       a.trial_scratch + (uint64_t)s * 3u * a.trial_slot_bytes, a.trial_slot_bytes, lds);
+    } else {
     if constexpr (TRIALS) { /* reference src/aad_encoder.c:863-871; a separate instantiation so that the
                              * trial-free kernel does not carry the search's registers */
       if constexpr (QUAD) L = to_quad(F, tap); else L = F;
-      if constexpr (DUAL) search_best_lane_dual<BITS, CHF, MS>(L, src, first, n, spb, a.trials, ch, c, tap, role, lds);
-      else search_best_lane<BITS, CHF, MS, QUAD>(L, src, first, n, spb, a.trials, ch, c, tap, lds);
+      search_best_lane<BITS, CHF, MS, QUAD>(L, src, first, n, spb, a.trials, ch, c, tap, lds);
       if constexpr (QUAD) F = from_quad<kEncTM>(L); else F = L;
     }
     seed_history(F, src, first, n);
@@ -977,10 +1146,9 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
     const uint32_t deferred = write_block_header(F, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh, writer, defer3);
     if constexpr (QUAD) L = to_quad(F, tap); else L = F;
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
-    /* dual: role 1 runs the encode pass as well (it holds the same state; only role 0 stores),
-     * which also leaves it with the right state for the next block */
     (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd, defer3, deferred);
     if constexpr (QUAD) F = from_quad<kEncTM>(L); else F = L;
+    }
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   }
 

@@ -76,6 +76,10 @@ struct AADHipContext {
    * plan of the context: their runs are ordered by the context's one stream */
   int32_t *d_residual;
   uint64_t residual_capacity;
+  /* scratch of the dual trial search (three block-sized slots per stream, aad_encode.hip.h
+   * encode_block_dual), grow-only, shared by the context's encode launches like d_residual */
+  uint8_t *d_trial;
+  uint64_t trial_capacity;
   /* AADHip_ContextSetOption; the defaults come from the environment ONCE, at creation */
   int32_t lane_mapping; /* enum AADHipLaneMapping */
   int32_t trial_lanes;  /* enum AADHipTrialLanes */
@@ -247,8 +251,14 @@ void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipSt
 bool pick_dual(const AADHipContext *ctx, const aad::EncodeArgs &a, bool quad)
 {
   if (!quad || a.trials == 0) return false;
+  if (a.trial_scratch == nullptr) return false; /* run_encode could not provide the slots */
   return ctx->trial_lanes != AAD_HIP_TRIAL_LANES_SINGLE;
 }
+
+/* the dual trial search keeps up to two alternative encodes of a block (and what measuring lanes write)
+ * beside the image: three slots of one block per stream */
+constexpr uint64_t kMaxTrialScratchBytes = 1ull << 30;
+uint32_t trial_slot_bytes(const aad::EncodeArgs &a) { return (a.block_size + 16u + 63u) & ~63u; }
 
 template <int BITS>
 void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
@@ -447,9 +457,30 @@ AADApiResult decode_plan_init(const struct AADHeaderInfo *format, int32_t has_fi
 }
 
 /* launch with fully populated arguments (device pointers set) on the context's stream */
-AADApiResult run_encode(AADHipContext *ctx, const aad::EncodeArgs &a)
+AADApiResult run_encode(AADHipContext *ctx, const aad::EncodeArgs &args)
 {
-  if (a.num_streams == 0) return AAD_APIRESULT_OK;
+  if (args.num_streams == 0) return AAD_APIRESULT_OK;
+  aad::EncodeArgs a = args;
+  a.trial_scratch = nullptr;
+  a.trial_slot_bytes = 0;
+  if (a.trials != 0 && a.channels <= 2 && ctx->trial_lanes != AAD_HIP_TRIAL_LANES_SINGLE &&
+      pick_quad(ctx, (uint64_t)a.num_streams * a.channels, a.channels, a.bits)) {
+    const uint64_t want = (uint64_t)a.num_streams * 3u * trial_slot_bytes(a);
+    if (want <= kMaxTrialScratchBytes) { /* else: the search and the encode one after the other on the same lanes */
+      if (ctx->trial_capacity < want) {
+        if (ctx->d_trial) {
+          if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize")) return AAD_APIRESULT_NG;
+          (void)hipFree(ctx->d_trial);
+          ctx->d_trial = nullptr;
+          ctx->trial_capacity = 0;
+        }
+        if (!hip_ok(ctx, hipMalloc((void **)&ctx->d_trial, want), "hipMalloc trial scratch")) return AAD_APIRESULT_NG;
+        ctx->trial_capacity = want;
+      }
+      a.trial_scratch = ctx->d_trial;
+      a.trial_slot_bytes = trial_slot_bytes(a);
+    }
+  }
   switch (a.bits) {
     case 4: launch_encode<4>(ctx, a); break;
     case 3: launch_encode<3>(ctx, a); break;
@@ -547,6 +578,8 @@ AADApiResult AADHip_ContextCreate(int32_t device_index, void *hip_stream, struct
   ctx->scratch_capacity = 0;
   ctx->d_residual = nullptr;
   ctx->residual_capacity = 0;
+  ctx->d_trial = nullptr;
+  ctx->trial_capacity = 0;
   ctx->pool = nullptr;
   ctx->staging_threads = 0;
   ctx->tile_bytes = 0;
@@ -596,6 +629,7 @@ void AADHip_ContextDestroy(struct AADHipContext *ctx)
       }
       if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
       if (ctx->d_residual) (void)hipFree(ctx->d_residual);
+      if (ctx->d_trial) (void)hipFree(ctx->d_trial);
       if (ctx->d_state) (void)hipFree(ctx->d_state);
       if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     }

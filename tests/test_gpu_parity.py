@@ -191,6 +191,31 @@ def test_ragged_batch_vs_oracle(engine, bits, channels, mapping):
             assert np.array_equal(d, ob.decode(img)[0]), (i, lens[i])
 
 
+@pytest.mark.parametrize("bits", [4, 3, 2])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_dual_trial_search_encodes_beside_the_chain(engine, bits, channels):
+    """The dual trial search (aad_encode.hip.h encode_block_dual) encodes every candidate while the chain
+    still measures and moves the winners' bytes from scratch slots into the image, channel by channel:
+    1-3 trials, first / later / short last blocks, block sizes whose bodies are not multiples of the
+    12-byte pieces, M/S, against the oracle.  Both trial-lane layouts must give the same bytes."""
+    rng = np.random.default_rng(4242 + bits * 10 + channels)
+    kinds = ["music", "noise", "nyquist"]
+    for trials in (1, 2, 3):
+        for ms, mbs in ((False, 18 * channels + 29), (channels == 2, 200), (False, 1024)):
+            lens = [3, 4, 5, 17, 64] + [int(v) for v in rng.integers(20, 6000, 27)]
+            pcms = [synth_pcm(1, n, channels, seed=7000 + i, kind=kinds[i % 3])[0] for i, n in enumerate(lens)]
+            param = make_parameter(channels, bits, mbs, 48000, ms, trials)
+            want = [ob.encode(p, bits, mbs, 48000, ms, trials) for p in pcms]
+            try:
+                for layout in ("dual", "single"):
+                    engine.set_mapping("quad", trial_lanes=layout)
+                    images = engine.encode_host(pcms, param)
+                    for i, img in enumerate(images):
+                        assert img == want[i], (layout, i, lens[i], trials, ms, mbs)
+            finally:
+                engine.set_mapping("auto", trial_lanes="dual")
+
+
 def test_staging_threads_do_not_change_bytes(engine):
     """Host-memory batches above a megabyte are staged by helper threads (AAD_HIP_OPTION_STAGING_THREADS);
     a ragged 12 MB batch - several chunks' worth at 8 threads' ranges, one 1.2 MB stream among short
