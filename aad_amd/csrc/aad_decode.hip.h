@@ -273,6 +273,39 @@ struct ChunkCodes {
   }
 };
 
+/* The same for any channel count: the chunk's units of channel c sit UB * channels bytes apart, so they
+ * are fetched byte by byte (8 / 6 / 4 loads per chunk) - still one chunk ahead of the arithmetic, like
+ * the wide loads above.  `p` points at the first byte of the chunk's first unit of channel c. */
+template <int BITS>
+struct ChunkCodesAny {
+  static constexpr int kUB = Pack<BITS>::kUnitBytes, kUnits = kChunk / Pack<BITS>::kUnitSamples, kBytes = kUnits * kUB;
+  uint32_t b[kBytes];
+  __device__ __forceinline__ void load(const uint8_t *p, uint32_t unit_stride)
+  {
+#pragma unroll
+    for (int u = 0; u < kUnits; u++)
+#pragma unroll
+      for (int q = 0; q < kUB; q++) b[u * kUB + q] = p[(uint32_t)u * unit_stride + q];
+  }
+  __device__ __forceinline__ void touch() /* see ChunkCodes::touch */
+  {
+    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+    if (kBytes == 6) asm volatile("" : "+v"(b[kBytes - 2]), "+v"(b[kBytes - 1]) :: "memory");
+    if (kBytes == 8) asm volatile("" : "+v"(b[kBytes - 4]), "+v"(b[kBytes - 3]), "+v"(b[kBytes - 2]), "+v"(b[kBytes - 1]) :: "memory");
+  }
+  /* big-endian code words, as ChunkCodes::unpack leaves them */
+  __device__ __forceinline__ void unpack(uint32_t *w) const
+  {
+    if (BITS == 3) {
+      w[0] = (b[0] << 16) | (b[1] << 8) | b[2];
+      w[1] = (b[3] << 16) | (b[4] << 8) | b[5];
+    } else {
+      w[0] = (b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3];
+      if (BITS == 4) w[1] = (b[4] << 24) | (b[5] << 16) | (b[6] << 8) | b[kBytes - 1];
+    }
+  }
+};
+
 /* Write 16 decoded samples of channel c (y[], int16 range) as interleaved PCM.  Mono: two 16-byte
  * stores.  Stereo: the two lanes of a pair trade half of their packed samples through DPP and
  * each writes 2 x 16 contiguous bytes of L/R frames.  A vector-memory instruction costs a lone
@@ -455,7 +488,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
   if constexpr (QUAD) L = to_quad<false>(H, tap); else L = H;
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
-  if (CHF != 0) {
+  if constexpr (CHF != 0) {
     /* full 16-sample chunks whose wide load stays inside the stream's bytes */
     using CC = ChunkCodes<BITS, (CHF ? CHF : 1)>;
     constexpr uint32_t kStride = Pack<BITS>::kChunkBytes * (CHF ? CHF : 1);
@@ -551,10 +584,38 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       }
     }
     done += full * kChunk;
+  } else {
+    /* any channel count (BASELINE config 4: eight): whole 16-sample chunks through the pipelined body,
+     * their code bytes fetched one chunk ahead (byte loads, the units of a channel are UB * channels
+     * apart), as many as lie completely inside the bytes that are there */
+    using CA = ChunkCodesAny<BITS>;
+    const uint32_t body = (uint32_t)kBlockHeaderBytesPerCh * ch;
+    const uint32_t unit_stride = UB * ch, row = CA::kUnits * unit_stride; /* one chunk of every channel */
+    uint32_t full = coded / kChunk;
+    const uint32_t fit = avail > body ? (avail - body) / row : 0u;
+    full = full < fit ? full : fit;
+    const uint8_t *cp = src + body + c * UB;
+    int16_t *op = a.pcm + sd.pcm_offset + (first + kTaps) * ch;
+    CA next;
+    for (auto &v : next.b) v = 0;
+    if (full) next.load(cp, unit_stride);
+    next.touch();
+    for (uint32_t k = 0; k < full; k++) {
+      uint32_t w[2] = {0, 0};
+      next.unpack(w);
+      if (k + 1 < full) cp += row; /* unconditional prefetch: the last iteration re-reads its own chunk */
+      next.load(cp, unit_stride);
+      int32_t y[kChunk];
+      decode_chunk16<BITS>(L, w, lds, y, finish);
+      next.touch();
+      store_chunk_pcm<0, false>(op, y, c, ch);
+      op += (uint64_t)kChunk * ch;
+    }
+    done += full * kChunk;
   }
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
-  /* remaining units (all of them when CHF == 0): byte loads, bytes past the stream read as zero */
+  /* remaining units: byte loads, bytes past the stream read as zero */
   {
     const uint32_t unit_stride = UB * ch;
     const uint32_t base = (uint32_t)kBlockHeaderBytesPerCh * ch + c * UB;
