@@ -93,7 +93,7 @@ enum AADHipLaneMapping {
   AAD_HIP_LANE_MAPPING_QUAD_FUSED = 3 /* four lanes per recurrence; decode: one fused kernel */
 };
 enum AADHipTrialLanes {
-  AAD_HIP_TRIAL_LANES_DUAL = 0,  /* trial search on the quad mapping: the probe pass on lanes of its own */
+  AAD_HIP_TRIAL_LANES_DUAL = 0,  /* trial search on the quad mapping: a second group of lanes runs the probe and encodes every candidate beside the chain */
   AAD_HIP_TRIAL_LANES_SINGLE = 1 /* both strands on the same lanes */
 };
 AADApiResult AADHip_ContextSetOption(struct AADHipContext *context, int32_t option, int32_t value);
