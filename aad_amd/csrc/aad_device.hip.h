@@ -381,10 +381,15 @@ __device__ __forceinline__ int32_t lms_shift_predict(Lane &L, int32_t qd, int32_
   pin64(acc);
   const int32_t w2 = lms_tap(L.w2, q14, L.h2);
   acc += (uint64_t)(uint32_t)L.h1 * (uint64_t)(uint32_t)w2;
-  pin64(acc);
-  const int32_t w3 = lms_tap(L.w3, q14, L.h3);
+  /* The last tap's increment is pinned together with the sum and nothing is pinned behind the last
+   * multiply-add: an instruction that reads a pinned value right behind the pin gets an s_nop in front of
+   * it (the hazard recogniser pads every inline-asm result) - with a pin of the sum alone here and a fourth
+   * one at the end, the last multiply-add and the final shift each did, and a latency-bound launch pays
+   * an issue slot for each.  (No pin at all: the last two products become v_mul_lo_u32, quarter rate.) */
+  int32_t inc3 = (int32_t)(((int64_t)q14 * (int64_t)L.h3 + (int64_t)(1ll << 28)) >> 32);
+  asm volatile("" : "+v"(acc), "+v"(inc3));
+  const int32_t w3 = (int32_t)((uint32_t)L.w3 + (uint32_t)inc3);
   acc += (uint64_t)(uint32_t)L.h2 * (uint64_t)(uint32_t)w3;
-  pin64(acc);
   L.h3 = L.h2;
   L.h2 = L.h1;
   L.h1 = L.h0;

@@ -121,18 +121,21 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     /* A */
     const uint32_t step9 = e.x; /* step << kWideStepShift (stage_tables), 24 bits at most */
     const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)), Pack<BITS>::kMagMax);
-    const uint32_t m21 = (mag << 1) | 1u;
-    const int32_t delta = *reinterpret_cast<const int16_t *>(lds + (kLdsDelta4Off - 1) + m21); /* 4 * delta */
+    const int32_t delta = *reinterpret_cast<const int16_t *>(lds + kLdsDelta4Off + (mag << 1)); /* 4 * delta */
     __builtin_amdgcn_sched_barrier(0);
-    /* B */
-    const int32_t q = (int32_t)(__umul24(step9, m21) >> (BITS - 1 + kWideStepShift)); /* (step * (2 mag + 1)) >> (BITS - 1) */
+    /* B: (step * (2 mag + 1)) >> (BITS - 1) as ONE high multiply on the 24-bit multiplier, as in the quad body */
+    const uint32_t m21s = (mag << (25 - BITS)) | (1u << (24 - BITS));
+    uint32_t code = 0;
+    if (EMIT) { /* pinned HERE, several instructions in front of its reader: no s_nop behind the pin */
+      code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
+      pin(code);
+    }
+    const int32_t q = (int32_t)(uint32_t)(((uint64_t)(step9 & 0xFFFFFFu) * (uint64_t)(m21s & 0xFFFFFFu)) >> 32); /* v_mul_hi_u32_u24 */
     const int32_t qd = (q ^ m) - m;
     const int32_t y = clip16(qd + p);
     if (EMIT) {
       uint32_t &acc = w[j / Pack<BITS>::kCodesPerWord];
-      uint32_t code = ((uint32_t)m & Pack<BITS>::kSign) | mag; /* v_and_or_b32 */
-      pin(code);
-      acc = (acc << BITS) | code;                               /* v_lshl_or_b32 */
+      acc = (acc << BITS) | code; /* v_lshl_or_b32 */
       pin(acc);
     } else {
       sq += wrapped_square(qd);
