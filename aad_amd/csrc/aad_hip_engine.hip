@@ -268,7 +268,10 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
   const bool quad = pick_quad(ctx, lanes, a.channels, BITS);
   const bool dual = pick_dual(ctx, a, quad);
   const uint64_t threads = quad ? lanes * (dual ? 8 : 4) : lanes;
-  const unsigned wg = pick_workgroup(threads);
+  /* dual: eight lanes per recurrence put a wave on twice as many CUs as the trial-free launch; two waves
+   * per workgroup (two SIMDs of one CU) keep a small batch on half the chip, so that a decode launched
+   * beside it finds free CUs (bench.py's pipelined step with trials 2: 158 -> see DESIGN.md) */
+  const unsigned wg = dual && threads <= 64ull * 1024ull ? 128u : pick_workgroup(threads);
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
   if (a.trials) {
     if (dual) launch_encode_mapped<BITS, true, true, true>(a, grid, block, stream);

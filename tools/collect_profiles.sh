@@ -17,6 +17,9 @@ rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GU
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -- $CMD > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -- $CMD > $O/write.log 2>&1
 python3 tools/kernel_stats_db.py $O/kt $O/kernel_stats.csv | head -6
+# every kernel of the full line (trials 2 = the dual trial-search encoder, the other BASELINE shapes)
+rocprofv3 --kernel-trace --stats -d $O/kt_full -- python3 bench.py --no-saturated --no-cpu-baseline > $O/kt_full.log 2>&1
+python3 tools/kernel_stats_db.py $O/kt_full $O/kernel_stats_full.csv | head -12
 python3 tools/pmc_db_summary.py $O 2 > $O/pmc_summary.txt
 python3 tools/hbm_traffic.py $O/fetch $O/write 1000 992 $O/hbm_traffic.json
 cp $O/hbm_traffic.json profiles/r02_hbm_traffic.json   # so that the bench line below quotes THIS measurement
