@@ -306,6 +306,45 @@ struct ChunkCodesAny {
   }
 };
 
+/* Mono, dense mapping: the code bytes of EIGHT chunks (64 / 48 / 32 bytes for 4- / 3- / 2-bit codes) with one
+ * group of wide loads.  A lane that fetches its 8 (6, 4) bytes chunk by chunk comes back to the same 64-byte
+ * sector eight times, microseconds apart on a full chip - with one sector per lane in flight the L2 cannot hold
+ * them, and the saturated mono decoder fetched 5.6x its code bytes (tools/saturated_traffic.sh).  Eight chunks
+ * at a time a sector is visited twice (the code bytes start 49 bytes into an image: a group straddles). */
+template <int BITS>
+struct GroupCodes {
+  static constexpr int kChunks = 8, kBytes = kChunks * Pack<BITS>::kChunkBytes, kDwords = kBytes / 4, kVec = kDwords / 4;
+  uint32_t d[kDwords];
+  __device__ __forceinline__ void load(const uint8_t *p)
+  {
+#pragma unroll
+    for (int v = 0; v < kVec; v++) {
+      const u32x4 q = reinterpret_cast<const U32x4 *>(p + 16 * v)->v;
+      d[4 * v] = q.x; d[4 * v + 1] = q.y; d[4 * v + 2] = q.z; d[4 * v + 3] = q.w;
+    }
+  }
+  __device__ __forceinline__ void touch() /* see ChunkCodes::touch */
+  {
+#pragma unroll
+    for (int v = 0; v < kVec; v++) asm volatile("" : "+v"(d[4 * v]), "+v"(d[4 * v + 1]), "+v"(d[4 * v + 2]), "+v"(d[4 * v + 3]) :: "memory");
+  }
+  /* big-endian code words of chunk i (compile-time after unrolling), as ChunkCodes<BITS, 1>::unpack leaves them */
+  __device__ __forceinline__ void unpack(int i, uint32_t *w) const
+  {
+    if (BITS == 4) {
+      w[0] = perm(0, d[2 * i], 0x00010203);
+      w[1] = perm(0, d[2 * i + 1], 0x00010203);
+    } else if (BITS == 2) {
+      w[0] = perm(0, d[i], 0x00010203);
+    } else { /* six bytes from byte 6 i: dword-aligned for even i, two bytes in for odd i */
+      const int q = (6 * i) / 4;
+      const uint32_t lo = d[q], hi = d[q + 1 < kDwords ? q + 1 : q];
+      w[0] = perm(hi, lo, (i & 1) ? 0x0c020304u : 0x0c000102u);
+      w[1] = perm(hi, lo, (i & 1) ? 0x0c050607u : 0x0c030405u);
+    }
+  }
+};
+
 /* Write 16 decoded samples of channel c (y[], int16 range) as interleaved PCM.  Mono: two 16-byte
  * stores.  Stereo: the two lanes of a pair trade half of their packed samples through DPP and
  * each writes 2 x 16 contiguous bytes of L/R frames.  A vector-memory instruction costs a lone
@@ -569,6 +608,40 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         return pack_chunk_pcm<(CHF ? CHF : 1), false>(y, c);
       };
       uint32_t k = 0;
+      if constexpr (CHF == 1) {
+        /* groups of eight chunks while they last (GroupCodes): `next` is refilled for what follows */
+        using GC = GroupCodes<BITS>;
+        const uint32_t groups = full / GC::kChunks;
+        if (groups) {
+          GC cur, nxt;
+          cur.load(cp);
+          for (uint32_t g = 0; g < groups; g++) {
+            if (g + 1 < groups) cp += GC::kBytes; /* unconditional prefetch: the last group re-reads itself */
+            nxt.load(cp);
+            static_for<0, GC::kChunks / 2>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              uint32_t wa[2] = {0, 0}, wb[2] = {0, 0};
+              cur.unpack(2 * i, wa);
+              cur.unpack(2 * i + 1, wb);
+              int32_t y[kChunk];
+              decode_chunk16<BITS>(L, wa, lds, y, finish);
+              const ChunkPcm a = pack_chunk_pcm<1, false>(y, c);
+              decode_chunk16<BITS>(L, wb, lds, y, finish);
+              const ChunkPcm b = pack_chunk_pcm<1, false>(y, c);
+              put_chunk_pcm<1, NT>(op, a, c);
+              put_chunk_pcm<1, NT>(op + (uint64_t)kChunk * ch, b, c);
+              op += (uint64_t)2 * kChunk * ch;
+            });
+            nxt.touch();
+#pragma unroll
+            for (int j = 0; j < GC::kDwords; j++) cur.d[j] = nxt.d[j];
+          }
+          k = groups * GC::kChunks;
+          cp += GC::kBytes; /* the last group was its own prefetch */
+          if (k < full) next.load(cp);
+          next.touch();
+        }
+      }
       /* stereo chunks are whole granules already and the pairing costs a latency-bound launch 2 %
        * (1000 x 16 blocks: 71.2 -> 72.9 us) for 2.6 % at saturation: mono only */
       for (; CHF == 1 && k + 2 <= full; k += 2) {
