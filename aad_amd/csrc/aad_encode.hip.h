@@ -494,6 +494,91 @@ __device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w
   }
 }
 
+/*
+ * Mono, dense mapping: the code bytes of eight chunks leave together.  A lane that stores its 8 (6, 4) bytes
+ * chunk by chunk comes back to the same 64-byte sector eight times, microseconds apart on a full chip - the L2
+ * cannot hold a sector per lane that long, every piece reached memory as a write of its own and the saturated
+ * mono encoder wrote 5.4x its code bytes (tools/saturated_traffic.sh).  The pieces wait in LDS instead of in
+ * registers (the chunk loop stays one body; a register version unrolls it eight times): piece k & 7 of lane l
+ * at [k & 7][l] - one conflict-free ds_write per chunk - and after every eighth chunk the lane reads its eight
+ * pieces back and stores 64 (48, 32) contiguous bytes with wide stores.  16 KB per workgroup of four waves.
+ */
+template <int BITS>
+struct MonoCodeStage {
+  static constexpr int kChunks = 8;
+  static constexpr int kPiece = BITS == 2 ? 4 : 8;         /* bytes per staged piece (3-bit: six used) */
+  static constexpr int kBytesPerWave = kChunks * 64 * kPiece;
+  static constexpr int kOut = kChunks * Pack<BITS>::kChunkBytes; /* bytes a full group stores */
+  char *base; /* this lane's column */
+  __device__ __forceinline__ void init(char *stage) { base = stage + (threadIdx.x >> 6) * kBytesPerWave + (threadIdx.x & 63u) * kPiece; }
+  /* w: the chunk's big-endian code words -> the bytes as they go to memory */
+  __device__ __forceinline__ void put(uint32_t k, const uint32_t *w)
+  {
+    char *at = base + (k & (kChunks - 1)) * (64 * kPiece);
+    if (BITS == 2) {
+      *reinterpret_cast<uint32_t *>(at) = perm(0, w[0], 0x00010203);
+    } else if (BITS == 4) {
+      u32x2 v;
+      v.x = perm(0, w[0], 0x00010203);
+      v.y = perm(0, w[1], 0x00010203);
+      *reinterpret_cast<u32x2 *>(at) = v;
+    } else { /* a0 a1 a2 a3 | a4 a5 - - : w0 = 0 a0 a1 a2, w1 = 0 a3 a4 a5 */
+      u32x2 v;
+      v.x = perm(w[1], w[0], 0x06000102);
+      v.y = perm(0, w[1], 0x0c0c0001);
+      *reinterpret_cast<u32x2 *>(at) = v;
+    }
+  }
+  __device__ __forceinline__ u32x2 piece(int j) const
+  {
+    if (BITS == 2) return u32x2{*reinterpret_cast<const uint32_t *>(base + j * (64 * kPiece)), 0u};
+    return *reinterpret_cast<const u32x2 *>(base + j * (64 * kPiece));
+  }
+  /* the eight pieces of a full group to `out` (any alignment) */
+  __device__ __forceinline__ void flush(uint8_t *out) const
+  {
+    if (BITS == 4) {
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const u32x2 a = piece(2 * v), b = piece(2 * v + 1);
+        reinterpret_cast<U32x4 *>(out + 16 * v)->v = u32x4{a.x, a.y, b.x, b.y};
+      }
+    } else if (BITS == 2) {
+#pragma unroll
+      for (int v = 0; v < 2; v++)
+        reinterpret_cast<U32x4 *>(out + 16 * v)->v = u32x4{piece(4 * v).x, piece(4 * v + 1).x, piece(4 * v + 2).x, piece(4 * v + 3).x};
+    } else { /* pairs of six-byte pieces -> three dwords */
+      uint32_t d[12];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const u32x2 a = piece(2 * j), b = piece(2 * j + 1);
+        d[3 * j] = a.x;
+        d[3 * j + 1] = perm(b.x, a.y, 0x05040100);
+        d[3 * j + 2] = perm(b.y, b.x, 0x05040302);
+      }
+#pragma unroll
+      for (int v = 0; v < 3; v++) reinterpret_cast<U32x4 *>(out + 16 * v)->v = u32x4{d[4 * v], d[4 * v + 1], d[4 * v + 2], d[4 * v + 3]};
+    }
+  }
+  /* piece j alone, as store_chunk_codes<BITS, 1> writes a chunk */
+  __device__ __forceinline__ void flush_one(int j, uint8_t *out) const
+  {
+    const u32x2 a = piece(j);
+    if (BITS == 2) {
+      reinterpret_cast<U32 *>(out)->v = a.x;
+    } else if (BITS == 4) {
+      reinterpret_cast<U32x2 *>(out)->v = a;
+    } else {
+      reinterpret_cast<U32 *>(out)->v = a.x;
+      reinterpret_cast<U16 *>(out + 4)->v = (uint16_t)a.y;
+    }
+  }
+};
+/* where the staging area starts in the encoders' LDS block, and the kernels that have one */
+constexpr int kLdsMonoStageOff = (kLdsBytesQuadEnc + 15) & ~15;
+template <int BITS, int CHF, bool QUAD>
+constexpr int kLdsBytesEncoder = (CHF == 1 && !QUAD) ? kLdsMonoStageOff + 4 * MonoCodeStage<BITS>::kBytesPerWave : kLdsBytesQuadEnc;
+
 /* the dense stereo 4-bit encode pass stores its codes four chunks at a time (run_block) */
 template <int BITS, int CHF, bool EMIT>
 constexpr bool kBurstStores = EMIT && CHF == 2 && BITS == 4;
@@ -747,6 +832,9 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
       constexpr bool PK = CHF != 0 && !MS;
       constexpr int kN = PK ? kChunk / 2 : kChunk;
       const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
+      constexpr bool kStage = EMIT && CHF == 1; /* mono: the codes of eight chunks leave together (MonoCodeStage) */
+      MonoCodeStage<BITS> stage;
+      if constexpr (kStage) stage.init(const_cast<char *>(lds) + kLdsMonoStageOff);
       for (uint32_t k = 0; k < full; k++) {
         int32_t x[kN];
 #pragma unroll
@@ -757,7 +845,10 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         uint32_t w[2] = {0, 0};
         encode_chunk16<BITS, EMIT, PK>(L, x, lds, w, last_qd, sq);
         next.touch();
-        if (EMIT) {
+        if constexpr (kStage) {
+          stage.put(k, w);
+          if ((k & 7u) == 7u) stage.flush(body + (uint64_t)(k - 7u) * kOutStride);
+        } else if (EMIT) {
           if (CHF != 0) {
             store_chunk_codes<BITS, (CHF ? CHF : 1), false>(body + (uint64_t)k * kOutStride * ch, w, c);
           } else { /* any channel count: this lane's unit bytes one by one */
@@ -772,6 +863,10 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
             }
           }
         }
+      }
+      if constexpr (kStage) { /* the chunks of the last, incomplete group */
+        const uint32_t rem = full & 7u;
+        for (uint32_t j = 0; j < rem; j++) stage.flush_one((int)j, body + (uint64_t)(full - rem + j) * kOutStride);
       }
       done = full * kChunk;
     }
@@ -1074,7 +1169,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytesQuadEnc]; /* dense and quad encoders share the four-copy wide table */
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytesEncoder<BITS, CHF, QUAD>]; /* dense and quad encoders share the four-copy wide table; mono dense: + code staging */
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, true, kWideStepShift, true>(lds);
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);

@@ -196,13 +196,6 @@ bool upload(AADHipContext *ctx, T **dst, const T *src, size_t count)
  * workgroups so four waves share one LDS copy of the tables. */
 unsigned pick_workgroup(uint64_t threads) { return threads <= 64ull * 1024ull ? 64u : 256u; }
 
-/* EXPERIMENT: extra dynamic LDS per workgroup of the dense launches (caps the waves per SIMD) */
-unsigned debug_dyn_lds()
-{
-  static const unsigned v = [] { const char *e = getenv("AAD_HIP_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-  return v;
-}
-
 /* Lane mapping by batch size.  "quad" (four lanes per recurrence, fewer instructions on the
  * recurrence's critical path) while the batch cannot fill the chip anyway, "dense" (one lane per
  * recurrence, fewest total instructions) beyond; the decoder has the split quad kernel below the
@@ -243,13 +236,13 @@ template <int BITS, bool QUAD, bool TRIALS, bool DUAL>
 void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
 {
   if (a.channels == 1)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD, TRIALS, DUAL>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD, TRIALS, DUAL>), grid, block, 0, stream, a);
   else if (a.channels == 2 && a.mid_side)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD, TRIALS, DUAL>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD, TRIALS, DUAL>), grid, block, 0, stream, a);
   else if (a.channels == 2)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD, TRIALS, DUAL>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD, TRIALS, DUAL>), grid, block, 0, stream, a);
   else if constexpr (!QUAD)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS, false>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS, false>), grid, block, 0, stream, a);
 }
 
 /* On the quad mapping the trial search's probe strand gets lanes of its own ("dual"): one pass of
@@ -294,26 +287,26 @@ template <int BITS, bool QUAD>
 void launch_decode_mapped(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
 {
   if (a.channels == 1)
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 1, false, QUAD>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 1, false, QUAD>), grid, block, 0, stream, a);
   else if (a.channels == 2 && a.mid_side) {
     if constexpr (!QUAD && BITS != 3) {
       if (a.stream_stores) {
-        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, false, true>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, false, true>), grid, block, 0, stream, a);
         return;
       }
     }
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, QUAD>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, QUAD>), grid, block, 0, stream, a);
   } else if (a.channels == 2) {
     if constexpr (!QUAD && BITS != 3) {
       if (a.stream_stores) {
-        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, false, true>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, false, true>), grid, block, 0, stream, a);
         return;
       }
     }
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, QUAD>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, QUAD>), grid, block, 0, stream, a);
   }
   else if constexpr (!QUAD)
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false, false>), grid, block, QUAD ? 0u : debug_dyn_lds(), stream, a);
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false, false>), grid, block, 0, stream, a);
 }
 
 /* Quad decode runs its two strands on different lanes (aad_decode_split.hip.h) unless
