@@ -835,7 +835,56 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
       constexpr bool kStage = EMIT && CHF == 1; /* mono: the codes of eight chunks leave together (MonoCodeStage) */
       MonoCodeStage<BITS> stage;
       if constexpr (kStage) stage.init(const_cast<char *>(lds) + kLdsMonoStageOff);
-      for (uint32_t k = 0; k < full; k++) {
+      uint32_t k0 = 0;
+      if constexpr (CHF == 1) {
+        /* mono: the samples of TWO chunks (64 bytes) with one group of loads, a pair ahead - a lane that reads
+         * 32 bytes per chunk visits every 64-byte sector of its stream three times, a chunk's worth of time apart
+         * (the saturated mono encoder fetched 2.2x its PCM), in pairs twice */
+        struct PairSamples {
+          uint32_t d[16];
+          __device__ __forceinline__ void load(const int16_t *x)
+          {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+              const u32x4 q = reinterpret_cast<const U32x4 *>(x + 8 * v)->v;
+              d[4 * v] = q.x; d[4 * v + 1] = q.y; d[4 * v + 2] = q.z; d[4 * v + 3] = q.w;
+            }
+          }
+          __device__ __forceinline__ void touch()
+          {
+#pragma unroll
+            for (int v = 0; v < 4; v++) asm volatile("" : "+v"(d[4 * v]), "+v"(d[4 * v + 1]), "+v"(d[4 * v + 2]), "+v"(d[4 * v + 3]) :: "memory");
+          }
+        };
+        const uint32_t pairs = full / 2;
+        if (pairs) {
+          PairSamples np;
+          np.load(xp);
+          for (uint32_t p = 0; p < pairs; p++, k0 += 2) {
+            int32_t xa[kChunk / 2], xb[kChunk / 2];
+#pragma unroll
+            for (int j = 0; j < kChunk / 2; j++) {
+              xa[j] = (int32_t)np.d[j];
+              xb[j] = (int32_t)np.d[kChunk / 2 + j];
+            }
+            if (p + 1 < pairs) xp += (uint64_t)2 * kChunk; /* unconditional prefetch: the last pair re-reads itself */
+            np.load(xp);
+            uint32_t wa[2] = {0, 0}, wb[2] = {0, 0};
+            encode_chunk16<BITS, EMIT, true>(L, xa, lds, wa, last_qd, sq);
+            encode_chunk16<BITS, EMIT, true>(L, xb, lds, wb, last_qd, sq);
+            np.touch();
+            if constexpr (kStage) {
+              stage.put(k0, wa);
+              stage.put(k0 + 1, wb);
+              if ((k0 & 7u) == 6u) stage.flush(body + (uint64_t)(k0 - 6u) * kOutStride);
+            }
+          }
+          xp += (uint64_t)2 * kChunk; /* the last pair was its own prefetch: now the chunk behind it */
+          if (k0 < full) next.load(xp, ch, c);
+          next.touch();
+        }
+      }
+      for (uint32_t k = k0; k < full; k++) {
         int32_t x[kN];
 #pragma unroll
         for (int j = 0; j < kN; j++) x[j] = PK ? (int32_t)next.pair(j, pair_sel) : next.get(j, c);
