@@ -546,6 +546,9 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
     next.r[0] = next.r[1] = next.r[2] = next.r[3] = 0;
     if (full || lead) next.load(cp);
     next.touch();
+    ChunkPcm lead_pcm;
+    lead_pcm.v[0] = lead_pcm.v[1] = u32x4{0, 0, 0, 0};
+    bool lead_pending = false;
     if constexpr (kLeadChunk) {
       if (lead) {
         uint32_t w[2] = {0, 0};
@@ -559,7 +562,12 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         y[3] = y3;
         decode_chunk16<BITS, (int)kLead>(L, w, lds, y + kTaps, finish);
         next.touch();
-        if (writer) store_chunk_pcm<CHF, QUAD, NT>(op - (uint64_t)kTaps * ch, y, c, ch); /* frames 0-15 of the block */
+        if constexpr (CHF == 1) { /* mono: 32 bytes - they wait for the next chunk's 32 (below): a whole 64-byte sector */
+          lead_pcm = pack_chunk_pcm<1, false>(y, c);
+          lead_pending = true;
+        } else {
+          if (writer) store_chunk_pcm<CHF, QUAD, NT>(op - (uint64_t)kTaps * ch, y, c, ch); /* frames 0-15 of the block */
+        }
         op += (uint64_t)kLead * ch;
         done = kLead;
       }
@@ -609,12 +617,28 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       };
       uint32_t k = 0;
       if constexpr (CHF == 1) {
+        /* the lead chunk's 32 bytes go out with chunk 0's: with the block's first frame on a 64-byte boundary
+         * that is sector 0, and every pair of chunks behind it (1-2, 3-4, ...) is a whole sector as well */
+        if (lead_pending) {
+          int16_t *lp = op - (uint64_t)(kLead + kTaps) * ch;
+          if (full) {
+            const ChunkPcm a = body(0);
+            put_chunk_pcm<1, NT>(lp, lead_pcm, c);
+            put_chunk_pcm<1, NT>(op, a, c);
+            op += (uint64_t)kChunk * ch;
+            k = 1;
+          } else {
+            put_chunk_pcm<1, NT>(lp, lead_pcm, c);
+          }
+        }
+      }
+      if constexpr (CHF == 1) {
         /* groups of eight chunks while they last (GroupCodes): `next` is refilled for what follows */
         using GC = GroupCodes<BITS>;
-        const uint32_t groups = full / GC::kChunks;
+        const uint32_t groups = (full - k) / GC::kChunks;
         if (groups) {
           GC cur, nxt;
-          cur.load(cp);
+          cur.load(cp); /* cp: chunk k's codes (body() leaves it there, with the same bytes in `next`) */
           for (uint32_t g = 0; g < groups; g++) {
             if (g + 1 < groups) cp += GC::kBytes; /* unconditional prefetch: the last group re-reads itself */
             nxt.load(cp);
@@ -636,7 +660,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
 #pragma unroll
             for (int j = 0; j < GC::kDwords; j++) cur.d[j] = nxt.d[j];
           }
-          k = groups * GC::kChunks;
+          k += groups * GC::kChunks;
           cp += GC::kBytes; /* the last group was its own prefetch */
           if (k < full) next.load(cp);
           next.touch();
