@@ -345,6 +345,44 @@ struct GroupCodes {
   }
 };
 
+/* Stereo, dense mapping: the same for a pair of lanes - 64 (48, 64) bytes of L/R-interleaved codes = four (four,
+ * eight) chunks per group of loads, both lanes of the pair reading the same bytes and keeping their own */
+template <int BITS>
+struct StereoGroupCodes {
+  static constexpr int kRaw = 2 * Pack<BITS>::kChunkBytes / 4;  /* dwords per chunk of the pair: 4 / 3 / 2 */
+  static constexpr int kChunks = BITS == 2 ? 8 : 4;
+  static constexpr int kDwords = kChunks * kRaw, kBytes = 4 * kDwords, kVec = kDwords / 4;
+  uint32_t d[kDwords];
+  __device__ __forceinline__ void load(const uint8_t *p)
+  {
+#pragma unroll
+    for (int v = 0; v < kVec; v++) {
+      const u32x4 q = reinterpret_cast<const U32x4 *>(p + 16 * v)->v;
+      d[4 * v] = q.x; d[4 * v + 1] = q.y; d[4 * v + 2] = q.z; d[4 * v + 3] = q.w;
+    }
+  }
+  __device__ __forceinline__ void touch()
+  {
+#pragma unroll
+    for (int v = 0; v < kVec; v++) asm volatile("" : "+v"(d[4 * v]), "+v"(d[4 * v + 1]), "+v"(d[4 * v + 2]), "+v"(d[4 * v + 3]) :: "memory");
+  }
+  /* big-endian code words of channel c in chunk i (compile-time), as ChunkCodes<BITS, 2>::unpack leaves them */
+  __device__ __forceinline__ void unpack(int i, uint32_t c, uint32_t *w) const
+  {
+    const uint32_t *r = d + i * kRaw;
+    if (BITS == 4) {
+      const uint32_t sel = 0x00020406u + c * 0x01010101u;
+      w[0] = perm(r[1], r[0], sel);
+      w[1] = perm(r[3], r[2], sel);
+    } else if (BITS == 2) {
+      w[0] = perm(r[1], r[0], 0x00020406u + c * 0x01010101u);
+    } else {
+      w[0] = perm(r[1], r[0], c ? 0x0c030405u : 0x0c000102u);
+      w[1] = perm(r[2], r[1], c ? 0x0c050607u : 0x0c020304u);
+    }
+  }
+};
+
 /* Write 16 decoded samples of channel c (y[], int16 range) as interleaved PCM.  Mono: two 16-byte
  * stores.  Stereo: the two lanes of a pair trade half of their packed samples through DPP and
  * each writes 2 x 16 contiguous bytes of L/R frames.  A vector-memory instruction costs a lone
@@ -668,6 +706,35 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       }
       /* stereo chunks are whole granules already and the pairing costs a latency-bound launch 2 %
        * (1000 x 16 blocks: 71.2 -> 72.9 us) for 2.6 % at saturation: mono only */
+      if constexpr (CHF == 2) {
+        /* groups of chunks while they last (StereoGroupCodes); every chunk's PCM is a whole 64-byte store already */
+        using SG = StereoGroupCodes<BITS>;
+        const uint32_t groups = (full - k) / SG::kChunks;
+        if (groups) {
+          SG cur, nxt;
+          cur.load(cp);
+          for (uint32_t g = 0; g < groups; g++) {
+            if (g + 1 < groups) cp += SG::kBytes; /* unconditional prefetch: the last group re-reads itself */
+            nxt.load(cp);
+            static_for<0, SG::kChunks>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              uint32_t w[2] = {0, 0};
+              cur.unpack(i, c, w);
+              int32_t y[kChunk];
+              decode_chunk16<BITS>(L, w, lds, y, finish);
+              put_chunk_pcm<2, NT>(op, pack_chunk_pcm<2, false>(y, c), c);
+              op += (uint64_t)kChunk * ch;
+            });
+            nxt.touch();
+#pragma unroll
+            for (int j = 0; j < SG::kDwords; j++) cur.d[j] = nxt.d[j];
+          }
+          k += groups * SG::kChunks;
+          cp += SG::kBytes; /* the last group was its own prefetch */
+          if (k < full) next.load(cp);
+          next.touch();
+        }
+      }
       for (; CHF == 1 && k + 2 <= full; k += 2) {
         const ChunkPcm a = body(k), b = body(k + 1);
         put_chunk_pcm<(CHF ? CHF : 1), NT>(op, a, c);
