@@ -502,82 +502,121 @@ __device__ __forceinline__ void store_chunk_codes(uint8_t *up, const uint32_t *w
  * registers (the chunk loop stays one body; a register version unrolls it eight times): piece k & 7 of lane l
  * at [k & 7][l] - one conflict-free ds_write per chunk - and after every eighth chunk the lane reads its eight
  * pieces back and stores 64 (48, 32) contiguous bytes with wide stores.  16 KB per workgroup of four waves.
+ * Stereo 3- and 2-bit codes the same way, the two lanes of a pair sharing the stores (4-bit stereo keeps its four
+ * chunks in registers, see kBurstStores).
  */
-template <int BITS>
-struct MonoCodeStage {
+template <int BITS, int CHF>
+struct CodeStage {
+  static_assert(CHF == 1 || (CHF == 2 && BITS != 4), "mono, and the stereo shapes without the register burst");
   static constexpr int kChunks = 8;
   static constexpr int kPiece = BITS == 2 ? 4 : 8;         /* bytes per staged piece (3-bit: six used) */
   static constexpr int kBytesPerWave = kChunks * 64 * kPiece;
-  static constexpr int kOut = kChunks * Pack<BITS>::kChunkBytes; /* bytes a full group stores */
-  char *base; /* this lane's column */
-  __device__ __forceinline__ void init(char *stage) { base = stage + (threadIdx.x >> 6) * kBytesPerWave + (threadIdx.x & 63u) * kPiece; }
-  /* w: the chunk's big-endian code words -> the bytes as they go to memory */
-  __device__ __forceinline__ void put(uint32_t k, const uint32_t *w)
+  static constexpr int kPieceOut = Pack<BITS>::kChunkBytes; /* bytes of a piece that go to memory */
+  char *base;  /* this lane's column */
+  char *pair0; /* stereo: the column of the pair's channel-0 lane */
+  __device__ __forceinline__ void init(char *stage)
+  {
+    char *wave = stage + (threadIdx.x >> 6) * kBytesPerWave;
+    base = wave + (threadIdx.x & 63u) * kPiece;
+    pair0 = wave + (threadIdx.x & 62u) * kPiece;
+  }
+  /* w: the chunk's big-endian code words of this lane's channel -> the lane's bytes as they go to memory
+   * (stereo: its half of the pair's interleaved bytes, as store_chunk_codes<BITS, 2> builds it) */
+  __device__ __forceinline__ void put(uint32_t k, const uint32_t *w, uint32_t c)
   {
     char *at = base + (k & (kChunks - 1)) * (64 * kPiece);
-    if (BITS == 2) {
-      *reinterpret_cast<uint32_t *>(at) = perm(0, w[0], 0x00010203);
-    } else if (BITS == 4) {
-      u32x2 v;
-      v.x = perm(0, w[0], 0x00010203);
-      v.y = perm(0, w[1], 0x00010203);
-      *reinterpret_cast<u32x2 *>(at) = v;
-    } else { /* a0 a1 a2 a3 | a4 a5 - - : w0 = 0 a0 a1 a2, w1 = 0 a3 a4 a5 */
-      u32x2 v;
-      v.x = perm(w[1], w[0], 0x06000102);
-      v.y = perm(0, w[1], 0x0c0c0001);
-      *reinterpret_cast<u32x2 *>(at) = v;
+    if (CHF == 1) {
+      if (BITS == 2) {
+        *reinterpret_cast<uint32_t *>(at) = perm(0, w[0], 0x00010203);
+      } else if (BITS == 4) {
+        *reinterpret_cast<u32x2 *>(at) = u32x2{perm(0, w[0], 0x00010203), perm(0, w[1], 0x00010203)};
+      } else { /* a0 a1 a2 a3 | a4 a5 - - : w0 = 0 a0 a1 a2, w1 = 0 a3 a4 a5 */
+        *reinterpret_cast<u32x2 *>(at) = u32x2{perm(w[1], w[0], 0x06000102), perm(0, w[1], 0x0c0c0001)};
+      }
+    } else if (BITS == 2) { /* pair: a0 b0 a1 b1 | a2 b2 a3 b3 ; lane c holds dword c */
+      const uint32_t other = pair_swap<false>(w[0], c);
+      const uint32_t A = c ? other : w[0], B = c ? w[0] : other;
+      *reinterpret_cast<uint32_t *>(at) = perm(A, B, c ? 0x00040105u : 0x02060307u);
+    } else { /* pair: a0 a1 a2 b0 b1 b2 | a3 a4 a5 b3 b4 b5 ; lane c holds six bytes c */
+      const uint32_t send = c ? w[0] : w[1], keep = c ? w[1] : w[0];
+      const uint32_t recv = pair_swap<false>(send, c);
+      const uint32_t A = c ? recv : keep, B = c ? keep : recv;
+      *reinterpret_cast<u32x2 *>(at) = u32x2{perm(A, B, 0x02040506), perm(A, B, 0x0c0c0001)};
     }
   }
-  __device__ __forceinline__ u32x2 piece(int j) const
+  __device__ __forceinline__ u32x2 piece(const char *col, int j) const
   {
-    if (BITS == 2) return u32x2{*reinterpret_cast<const uint32_t *>(base + j * (64 * kPiece)), 0u};
-    return *reinterpret_cast<const u32x2 *>(base + j * (64 * kPiece));
+    if (BITS == 2) return u32x2{*reinterpret_cast<const uint32_t *>(col + j * (64 * kPiece)), 0u};
+    return *reinterpret_cast<const u32x2 *>(col + j * (64 * kPiece));
   }
-  /* the eight pieces of a full group to `out` (any alignment) */
-  __device__ __forceinline__ void flush(uint8_t *out) const
+  /* two six-byte pieces -> three dwords */
+  __device__ __forceinline__ void six2(const u32x2 &a, const u32x2 &b, uint32_t *d) const
   {
-    if (BITS == 4) {
-#pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const u32x2 a = piece(2 * v), b = piece(2 * v + 1);
-        reinterpret_cast<U32x4 *>(out + 16 * v)->v = u32x4{a.x, a.y, b.x, b.y};
-      }
-    } else if (BITS == 2) {
-#pragma unroll
-      for (int v = 0; v < 2; v++)
-        reinterpret_cast<U32x4 *>(out + 16 * v)->v = u32x4{piece(4 * v).x, piece(4 * v + 1).x, piece(4 * v + 2).x, piece(4 * v + 3).x};
-    } else { /* pairs of six-byte pieces -> three dwords */
-      uint32_t d[12];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const u32x2 a = piece(2 * j), b = piece(2 * j + 1);
-        d[3 * j] = a.x;
-        d[3 * j + 1] = perm(b.x, a.y, 0x05040100);
-        d[3 * j + 2] = perm(b.y, b.x, 0x05040302);
-      }
-#pragma unroll
-      for (int v = 0; v < 3; v++) reinterpret_cast<U32x4 *>(out + 16 * v)->v = u32x4{d[4 * v], d[4 * v + 1], d[4 * v + 2], d[4 * v + 3]};
-    }
+    d[0] = a.x;
+    d[1] = perm(b.x, a.y, 0x05040100);
+    d[2] = perm(b.y, b.x, 0x05040302);
   }
-  /* piece j alone, as store_chunk_codes<BITS, 1> writes a chunk */
-  __device__ __forceinline__ void flush_one(int j, uint8_t *out) const
+  /* the pieces of a full group (chunks k0 .. k0 + 7, `group` = where chunk k0's bytes go) with wide stores.
+   * Mono: the lane's own eight pieces, 64 (48, 32) contiguous bytes.  Stereo: the pair's sixteen pieces
+   * alternate in memory - lane c stores the pair's chunks 4c .. 4c + 3, reading both columns. */
+  __device__ __forceinline__ void flush(uint8_t *group, uint32_t c) const
   {
-    const u32x2 a = piece(j);
-    if (BITS == 2) {
-      reinterpret_cast<U32 *>(out)->v = a.x;
-    } else if (BITS == 4) {
-      reinterpret_cast<U32x2 *>(out)->v = a;
+    if (CHF == 1) {
+      if (BITS == 4) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const u32x2 a = piece(base, 2 * v), b = piece(base, 2 * v + 1);
+          reinterpret_cast<U32x4 *>(group + 16 * v)->v = u32x4{a.x, a.y, b.x, b.y};
+        }
+      } else if (BITS == 2) {
+#pragma unroll
+        for (int v = 0; v < 2; v++)
+          reinterpret_cast<U32x4 *>(group + 16 * v)->v =
+              u32x4{piece(base, 4 * v).x, piece(base, 4 * v + 1).x, piece(base, 4 * v + 2).x, piece(base, 4 * v + 3).x};
+      } else {
+        uint32_t d[12];
+#pragma unroll
+        for (int j = 0; j < 4; j++) six2(piece(base, 2 * j), piece(base, 2 * j + 1), d + 3 * j);
+#pragma unroll
+        for (int v = 0; v < 3; v++) reinterpret_cast<U32x4 *>(group + 16 * v)->v = u32x4{d[4 * v], d[4 * v + 1], d[4 * v + 2], d[4 * v + 3]};
+      }
     } else {
-      reinterpret_cast<U32 *>(out)->v = a.x;
-      reinterpret_cast<U16 *>(out + 4)->v = (uint16_t)a.y;
+      const char *col0 = pair0 + (4 * c) * (64 * kPiece), *col1 = col0 + kPiece; /* chunk 4c of either channel */
+      uint8_t *out = group + (uint64_t)c * (4 * 2 * kPieceOut);
+      if (BITS == 2) {
+#pragma unroll
+        for (int v = 0; v < 2; v++)
+          reinterpret_cast<U32x4 *>(out + 16 * v)->v =
+              u32x4{piece(col0, 2 * v).x, piece(col1, 2 * v).x, piece(col0, 2 * v + 1).x, piece(col1, 2 * v + 1).x};
+      } else {
+        uint32_t d[12];
+#pragma unroll
+        for (int j = 0; j < 4; j++) six2(piece(col0, j), piece(col1, j), d + 3 * j);
+#pragma unroll
+        for (int v = 0; v < 3; v++) reinterpret_cast<U32x4 *>(out + 16 * v)->v = u32x4{d[4 * v], d[4 * v + 1], d[4 * v + 2], d[4 * v + 3]};
+      }
+    }
+  }
+  /* the lane's piece of chunk j of an incomplete group alone, as store_chunk_codes writes it; `at` = where it goes */
+  __device__ __forceinline__ void flush_one(int j, uint8_t *at) const
+  {
+    const u32x2 a = piece(base, j);
+    if (BITS == 2) {
+      reinterpret_cast<U32 *>(at)->v = a.x;
+    } else if (BITS == 4) {
+      reinterpret_cast<U32x2 *>(at)->v = a;
+    } else {
+      reinterpret_cast<U32 *>(at)->v = a.x;
+      reinterpret_cast<U16 *>(at + 4)->v = (uint16_t)a.y;
     }
   }
 };
-/* where the staging area starts in the encoders' LDS block, and the kernels that have one */
-constexpr int kLdsMonoStageOff = (kLdsBytesQuadEnc + 15) & ~15;
+/* which dense encoders stage their codes, where the staging area starts in their LDS block, and its size */
 template <int BITS, int CHF, bool QUAD>
-constexpr int kLdsBytesEncoder = (CHF == 1 && !QUAD) ? kLdsMonoStageOff + 4 * MonoCodeStage<BITS>::kBytesPerWave : kLdsBytesQuadEnc;
+constexpr bool kStagedCodes = !QUAD && (CHF == 1 || (CHF == 2 && BITS != 4));
+constexpr int kLdsCodeStageOff = (kLdsBytesQuadEnc + 15) & ~15;
+template <int BITS, int CHF, bool QUAD>
+constexpr int kLdsBytesEncoder = kStagedCodes<BITS, CHF, QUAD> ? kLdsCodeStageOff + 4 * 8 * 64 * (BITS == 2 ? 4 : 8) : kLdsBytesQuadEnc;
 
 /* the dense stereo 4-bit encode pass stores its codes four chunks at a time (run_block) */
 template <int BITS, int CHF, bool EMIT>
@@ -832,9 +871,9 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
       constexpr bool PK = CHF != 0 && !MS;
       constexpr int kN = PK ? kChunk / 2 : kChunk;
       const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
-      constexpr bool kStage = EMIT && CHF == 1; /* mono: the codes of eight chunks leave together (MonoCodeStage) */
-      MonoCodeStage<BITS> stage;
-      if constexpr (kStage) stage.init(const_cast<char *>(lds) + kLdsMonoStageOff);
+      constexpr bool kStage = EMIT && kStagedCodes<BITS, CHF, false>; /* the codes of eight chunks leave together (CodeStage) */
+      CodeStage<BITS, kStage ? CHF : 1> stage;
+      if constexpr (kStage) stage.init(const_cast<char *>(lds) + kLdsCodeStageOff);
       uint32_t k0 = 0;
       if constexpr (CHF == 1) {
         /* mono: the samples of TWO chunks (64 bytes) with one group of loads, a pair ahead - a lane that reads
@@ -874,9 +913,9 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
             encode_chunk16<BITS, EMIT, true>(L, xb, lds, wb, last_qd, sq);
             np.touch();
             if constexpr (kStage) {
-              stage.put(k0, wa);
-              stage.put(k0 + 1, wb);
-              if ((k0 & 7u) == 6u) stage.flush(body + (uint64_t)(k0 - 6u) * kOutStride);
+              stage.put(k0, wa, c);
+              stage.put(k0 + 1, wb, c);
+              if ((k0 & 7u) == 6u) stage.flush(body + (uint64_t)(k0 - 6u) * kOutStride, c);
             }
           }
           xp += (uint64_t)2 * kChunk; /* the last pair was its own prefetch: now the chunk behind it */
@@ -895,8 +934,8 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         encode_chunk16<BITS, EMIT, PK>(L, x, lds, w, last_qd, sq);
         next.touch();
         if constexpr (kStage) {
-          stage.put(k, w);
-          if ((k & 7u) == 7u) stage.flush(body + (uint64_t)(k - 7u) * kOutStride);
+          stage.put(k, w, c);
+          if ((k & 7u) == 7u) stage.flush(body + (uint64_t)(k - 7u) * kOutStride * ch, c);
         } else if (EMIT) {
           if (CHF != 0) {
             store_chunk_codes<BITS, (CHF ? CHF : 1), false>(body + (uint64_t)k * kOutStride * ch, w, c);
@@ -915,7 +954,8 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
       }
       if constexpr (kStage) { /* the chunks of the last, incomplete group */
         const uint32_t rem = full & 7u;
-        for (uint32_t j = 0; j < rem; j++) stage.flush_one((int)j, body + (uint64_t)(full - rem + j) * kOutStride);
+        for (uint32_t j = 0; j < rem; j++)
+          stage.flush_one((int)j, body + (uint64_t)(full - rem + j) * kOutStride * ch + (uint64_t)c * Pack<BITS>::kChunkBytes);
       }
       done = full * kChunk;
     }
