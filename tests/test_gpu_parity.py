@@ -216,6 +216,37 @@ def test_dual_trial_search_encodes_beside_the_chain(engine, bits, channels):
                 engine.set_mapping("auto", trial_lanes="dual")
 
 
+@pytest.mark.parametrize("bits", [4, 3, 2])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_dense_kernels_group_boundaries(engine, bits, channels):
+    """The dense kernels move code bytes in groups of chunks (decoder: GroupCodes / StereoGroupCodes, encoder:
+    CodeStage, paired sample loads, the mono decoder's lead chunk stored with chunk 0): block sizes that put 0 .. 20
+    whole chunks and every remainder behind the header, several blocks per stream and a ragged last one, M/S -
+    against the oracle, dense mapping forced."""
+    rng = np.random.default_rng(9100 + bits * 10 + channels)
+    engine.set_mapping("dense")
+    try:
+        for mbs in list(range(18 * channels + 3, 18 * channels + 3 + 170 * channels, 5 * channels + 1)) + [1024]:
+            rc, block_size, spb = ob.geometry(mbs, channels, bits)
+            if rc != 0:
+                continue
+            ms = bool(channels == 2 and mbs % 2)
+            lens = [spb, 2 * spb + 1, 3 * spb - 2, 3 * spb + int(rng.integers(5, max(6, spb)))]
+            pcms = [synth_pcm(1, n, channels, seed=9200 + i + mbs, kind=["music", "noise"][i % 2])[0] for i, n in enumerate(lens)]
+            try:
+                want = [ob.encode(p, bits, mbs, 48000, ms, 0) for p in pcms]
+            except RuntimeError:  # a block that would carry no data (reference src/aad_encoder.c:170-172)
+                continue
+            images = engine.encode_host(pcms, make_parameter(channels, bits, mbs, 48000, ms, 0))
+            for i, img in enumerate(images):
+                assert img == want[i], (mbs, i, lens[i])
+            decoded = engine.decode_host(images)
+            for i, (img, d) in enumerate(zip(images, decoded)):
+                assert np.array_equal(d, ob.decode(img)[0]), (mbs, i, lens[i])
+    finally:
+        engine.set_mapping("auto")
+
+
 def test_staging_threads_do_not_change_bytes(engine):
     """Host-memory batches above a megabyte are staged by helper threads (AAD_HIP_OPTION_STAGING_THREADS);
     a ragged 12 MB batch - several chunks' worth at 8 threads' ranges, one 1.2 MB stream among short
