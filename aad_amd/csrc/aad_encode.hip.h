@@ -1131,6 +1131,12 @@ __device__ __forceinline__ void encode_block_dual(Lane &F, int32_t &last_qd, con
   double best_rmse = 0.0, held_rmse = 0.0;
   uint32_t best_loc = kLocNone;
 
+  /* the first four samples of the two windows the passes start from, fetched once (every pass seeds its
+   * history from them: one round trip to memory per block instead of one per pass) */
+  Lane seed_cur = {0, 0, 0, 0, 0, 0, 0, 0, 0}, seed_prev = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  seed_history(seed_cur, src, first, n);
+  if (have_prev) seed_history(seed_prev, src, first - spb, spb);
+
   for (uint32_t p = 0; p < passes; p++) {
     /* ---- this lane's part in pass p */
     const bool chain_active = p < chain_passes;
@@ -1155,7 +1161,10 @@ __device__ __forceinline__ void encode_block_dual(Lane &F, int32_t &last_qd, con
 
     QuadLane Q = role != 0 ? from1 : run;
     Lane Ff = from_quad<kEncTM>(Q);
-    seed_history(Ff, src, wfirst, wn);
+    Ff.h0 = on_prev ? seed_prev.h0 : seed_cur.h0;
+    Ff.h1 = on_prev ? seed_prev.h1 : seed_cur.h1;
+    Ff.h2 = on_prev ? seed_prev.h2 : seed_cur.h2;
+    Ff.h3 = on_prev ? seed_prev.h3 : seed_cur.h3;
     Lane Fm = Ff;
     write_block_header(Fm, base + (uint64_t)c * kBlockHeaderBytesPerCh, enc && tap == 0);
     if (enc) Ff = Fm; /* an encode starts from the weights the header carries */
@@ -1221,24 +1230,28 @@ __device__ __forceinline__ void encode_block_dual(Lane &F, int32_t &last_qd, con
     const uint32_t used = (kBlockHeaderBytesPerCh + (coded + US - 1) / US * UB) * ch;
     const uint8_t *const s0 = place(loc0), *const s1 = place(loc1);
     const uint32_t pieces = used / 12u;
-    for (uint32_t q = id; q < pieces; q += kGroup) {
-      const u32x3 v0 = reinterpret_cast<const U32x3 *>(s0 + 12u * q)->v;
-      u32x3 out = v0;
-      if (CHF == 2) {
-        const u32x3 v1 = reinterpret_cast<const U32x3 *>(s1 + 12u * q)->v;
-        /* channel 0's bytes of the piece: 36 header bytes = pieces 0-2 (18 per channel), then whole
-         * units alternate (1 byte, or 3 for 3-bit codes: a 6-byte pattern, twice per piece) */
-        u32x3 m;
-        if (q == 0) m = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        else if (q == 1) m = u32x3{0xFFFFFFFFu, 0x0000FFFFu, 0u};
-        else if (q == 2) m = u32x3{0u, 0u, 0u};
-        else if (UB == 1) m = u32x3{0x00FF00FFu, 0x00FF00FFu, 0x00FF00FFu};
-        else m = u32x3{0x00FFFFFFu, 0xFFFF0000u, 0x000000FFu};
-        out.x = (v0.x & m.x) | (v1.x & ~m.x);
-        out.y = (v0.y & m.y) | (v1.y & ~m.y);
-        out.z = (v0.z & m.z) | (v1.z & ~m.z);
-      }
-      reinterpret_cast<U32x3 *>(img + 12u * q)->v = out;
+    /* channel 0's bytes of piece q: 36 header bytes = pieces 0-2 (18 per channel), then whole units alternate
+     * (1 byte, or 3 for 3-bit codes: a 6-byte pattern, twice per piece) */
+    auto mask0 = [&](uint32_t q) -> u32x3 {
+      if (CHF == 1 || q == 0) return u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+      if (q == 1) return u32x3{0xFFFFFFFFu, 0x0000FFFFu, 0u};
+      if (q == 2) return u32x3{0u, 0u, 0u};
+      if (UB == 1) return u32x3{0x00FF00FFu, 0x00FF00FFu, 0x00FF00FFu};
+      return u32x3{0x00FFFFFFu, 0xFFFF0000u, 0x000000FFu};
+    };
+    auto fetch = [&](const uint8_t *from, uint32_t q) { return reinterpret_cast<const U32x3 *>(from + 12u * q)->v; };
+    auto merged = [&](const u32x3 &v0, const u32x3 &v1, uint32_t q) {
+      const u32x3 m = mask0(q);
+      return u32x3{(v0.x & m.x) | (v1.x & ~m.x), (v0.y & m.y) | (v1.y & ~m.y), (v0.z & m.z) | (v1.z & ~m.z)};
+    };
+    /* three pieces per round, their loads issued together: a round costs one trip to memory, not three */
+    for (uint32_t q = id; q < pieces; q += 3u * kGroup) {
+      const uint32_t qb = q + kGroup < pieces ? q + kGroup : q, qc = q + 2u * kGroup < pieces ? q + 2u * kGroup : q;
+      const u32x3 a0 = fetch(s0, q), a1 = fetch(s1, q), b0 = fetch(s0, qb), b1 = fetch(s1, qb), c0 = fetch(s0, qc), c1 = fetch(s1, qc);
+      const u32x3 oa = merged(a0, a1, q), ob = merged(b0, b1, qb), oc = merged(c0, c1, qc);
+      reinterpret_cast<U32x3 *>(img + 12u * q)->v = oa;
+      if (qb != q) reinterpret_cast<U32x3 *>(img + 12u * qb)->v = ob;
+      if (qc != q) reinterpret_cast<U32x3 *>(img + 12u * qc)->v = oc;
     }
     for (uint32_t o = pieces * 12u + id; o < used; o += kGroup) { /* at most 11 bytes, all of them code bytes for stereo */
       const uint32_t owner = CHF == 2 ? ((o - kBlockHeaderBytesPerCh * ch) / UB) & 1u : 0u;
