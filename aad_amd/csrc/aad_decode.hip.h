@@ -554,7 +554,20 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
 
   /* the first four samples are stored verbatim in the header - reference :386-391 */
   const int32_t y0 = finish(H.h3), y1 = finish(H.h2), y2 = finish(H.h1), y3 = finish(H.h0);
-  if (writer && !lead) {
+  /* Mono 3-bit, dense mapping (no lead chunk: twelve 3-bit samples are one and a half units): the four verbatim
+   * samples - 8 bytes - are not stored by themselves but CARRIED in front of the first pair of chunks, whose last
+   * 8 bytes are carried in turn: every pair then goes out as the 64 bytes from 8 bytes in front of its first
+   * sample, a whole sector on a block whose first frame is 64-byte aligned, instead of 56 + 8 bytes of two. */
+  constexpr bool kCarryPcm = CHF == 1 && !QUAD && BITS == 3;
+  u32x2 pcm_carry = {0, 0};
+  bool carrying = false;
+  if constexpr (kCarryPcm) {
+    if (n > 3) {
+      pcm_carry = u32x2{perm((uint32_t)y1, (uint32_t)y0, 0x05040100), perm((uint32_t)y3, (uint32_t)y2, 0x05040100)};
+      carrying = true;
+    }
+  }
+  if (writer && !lead && !carrying) {
     if (n > 0) dst[0] = (int16_t)y0;
     if (n > 1) dst[ch] = (int16_t)y1;
     if (n > 2) dst[2 * ch] = (int16_t)y2;
@@ -653,6 +666,21 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         next.touch();
         return pack_chunk_pcm<(CHF ? CHF : 1), false>(y, c);
       };
+      /* a pair of mono chunks: two 32-byte halves back to back, or - carrying - the 64 bytes from 8 bytes in front */
+      auto emit_pair = [&](const ChunkPcm &a, const ChunkPcm &b) {
+        if (kCarryPcm && carrying) {
+          int16_t *at = op - (uint64_t)kTaps;
+          store_u32x4<false>(at, u32x4{pcm_carry.x, pcm_carry.y, a.v[0].x, a.v[0].y});
+          store_u32x4<false>(at + 8, u32x4{a.v[0].z, a.v[0].w, a.v[1].x, a.v[1].y});
+          store_u32x4<false>(at + 16, u32x4{a.v[1].z, a.v[1].w, b.v[0].x, b.v[0].y});
+          store_u32x4<false>(at + 24, u32x4{b.v[0].z, b.v[0].w, b.v[1].x, b.v[1].y});
+          pcm_carry = u32x2{b.v[1].z, b.v[1].w};
+        } else {
+          put_chunk_pcm<1, false>(op, a, c);
+          put_chunk_pcm<1, false>(op + (uint64_t)kChunk, b, c);
+        }
+        op += (uint64_t)2 * kChunk;
+      };
       uint32_t k = 0;
       if constexpr (CHF == 1) {
         /* the lead chunk's 32 bytes go out with chunk 0's: with the block's first frame on a 64-byte boundary
@@ -690,9 +718,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
               const ChunkPcm a = pack_chunk_pcm<1, false>(y, c);
               decode_chunk16<BITS>(L, wb, lds, y, finish);
               const ChunkPcm b = pack_chunk_pcm<1, false>(y, c);
-              put_chunk_pcm<1, NT>(op, a, c);
-              put_chunk_pcm<1, NT>(op + (uint64_t)kChunk * ch, b, c);
-              op += (uint64_t)2 * kChunk * ch;
+              emit_pair(a, b);
             });
             nxt.touch();
 #pragma unroll
@@ -735,11 +761,15 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
           next.touch();
         }
       }
-      for (; CHF == 1 && k + 2 <= full; k += 2) {
-        const ChunkPcm a = body(k), b = body(k + 1);
-        put_chunk_pcm<(CHF ? CHF : 1), NT>(op, a, c);
-        put_chunk_pcm<(CHF ? CHF : 1), NT>(op + (uint64_t)kChunk * ch, b, c);
-        op += (uint64_t)2 * kChunk * ch;
+      if constexpr (CHF == 1) {
+        for (; k + 2 <= full; k += 2) {
+          const ChunkPcm a = body(k), b = body(k + 1);
+          emit_pair(a, b);
+        }
+      }
+      if constexpr (kCarryPcm) { /* what is still carried: the 8 bytes in front of the next sample */
+        if (carrying) reinterpret_cast<U32x2 *>(op - (uint64_t)kTaps)->v = pcm_carry;
+        carrying = false;
       }
       for (; k < full; k++) {
         const ChunkPcm a = body(k);
