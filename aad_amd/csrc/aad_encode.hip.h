@@ -1170,8 +1170,16 @@ __device__ __forceinline__ void encode_block_dual(Lane &F, int32_t &last_qd, con
     if (enc) Ff = Fm; /* an encode starts from the weights the header carries */
     Q = to_quad(Ff, tap);
     int32_t qd = last_qd;
-    const int64_t sum = run_block<BITS, CHF, MS, true, kPassBoth>(Q, src, wfirst, wn, ch, c, tap == 0,
-                                                                  base + (uint64_t)kBlockHeaderBytesPerCh * ch, lds, qd, false, 0, enc);
+    /* What the wave needs from this pass (the same for all of its lanes): with a previous block, pass 0 is
+     * probe + previous block - sums only - and the even passes from 2 on are previous block + an encode -
+     * codes only (a whole block has no padding, so the chain's pass ends where a measuring one does); the
+     * leaner bodies save 3.2 and 1.6 issue slots per sample there. */
+    const bool sums_only = have_prev && p == 0, codes_only = have_prev && p >= 2 && (p & 1u) == 0;
+    uint8_t *const codes_at = base + (uint64_t)kBlockHeaderBytesPerCh * ch;
+    int64_t sum = 0;
+    if (sums_only) sum = run_block<BITS, CHF, MS, true, kPassRmse>(Q, src, wfirst, wn, ch, c, false, nullptr, lds, qd);
+    else if (codes_only) (void)run_block<BITS, CHF, MS, true, kPassEncode>(Q, src, wfirst, wn, ch, c, tap == 0, codes_at, lds, qd);
+    else sum = run_block<BITS, CHF, MS, true, kPassBoth>(Q, src, wfirst, wn, ch, c, tap == 0, codes_at, lds, qd, false, 0, enc);
     const double r = wn < (uint32_t)kTaps ? 0.0 : sqrt((double)sum / (double)wn);
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
