@@ -40,11 +40,21 @@ def _round_up(v, a):
 
 
 class BatchCodec:
-    def __init__(self, encode_fn=None, rank=0, world=1, dist=None, device="cpu", engine=None):
+    def __init__(self, encode_fn=None, rank=0, world=1, dist=None, device="cpu", engine=None, force_collectives=False):
         """encode_fn(list of int16 [samples, channels] arrays) -> list of bytes (host shards);
         engine: an aad_amd.Engine (device shards).  device: where collective tensors live -
-        "cuda:N" with the nccl backend, "cpu" with gloo."""
+        "cuda:N" with the nccl backend, "cpu" with gloo.
+        force_collectives: a world of one normally skips the broadcast and the gather (nothing to
+        exchange); with this flag it runs them anyway under its one-rank process group - the only way
+        to execute the RCCL calls (device-tensor broadcast / gather) on a one-GPU box."""
         self.encode_fn, self.rank, self.world, self.dist, self.device, self.engine = encode_fn, rank, world, dist, device, engine
+        self.force_collectives = bool(force_collectives)
+        if self.force_collectives and dist is None:
+            raise ValueError("force_collectives needs an initialised torch.distributed module")
+
+    def _alone(self):
+        """no peer to talk to, and nobody asked for the collectives to run regardless"""
+        return self.world == 1 and not self.force_collectives
 
     # ---- collectives ----------------------------------------------------------------------
     def _collective_device(self):
@@ -53,7 +63,7 @@ class BatchCodec:
     def broadcast_table(self, lengths, root=0):
         """lengths: samples per file on the root (ignored elsewhere) -> int64 array on every rank"""
         import torch
-        if self.world == 1:
+        if self._alone():
             return np.asarray(lengths, dtype=np.int64)
         dev = self._collective_device()
         n = torch.tensor([len(lengths) if self.rank == root else 0], dtype=torch.int64, device=dev)
@@ -134,7 +144,7 @@ class BatchCodec:
                 torch.cuda.current_stream().synchronize()
             finally:
                 plan.close()
-        if self.world == 1:
+        if self._alone():
             rows = send.cpu().numpy()[None, :]
         else:
             rows = self._gather_rows(send, root)
@@ -157,7 +167,7 @@ class BatchCodec:
         sizes = [int(image_size(int(lengths[i]))) for i in range(len(lengths))]
         for i, img in zip(mine, images):
             assert len(img) == sizes[i], "image size differs from the format arithmetic"
-        if self.world == 1:
+        if self._alone():
             return images
         offsets, row = self._row_layout(shards, sizes)  # sizes are static: no size exchange
         send = np.zeros(row, dtype=np.uint8)

@@ -35,17 +35,19 @@ __device__ __forceinline__ int32_t index_delta_arith(uint32_t mag)
   }
 }
 
-/* the same delta times kIdxScale (4), for the quad encoder's scaled step index */
+/* the same delta times kIdxScale, for the encoders' scaled step index (4-bit: the correction bytes
+ * kIdxScale * {20, 21, 22} still fit a byte at scale 8: 160, 168, 176) */
 template <int BITS>
-__device__ __forceinline__ int32_t index_delta_arith_x4(uint32_t mag)
+__device__ __forceinline__ int32_t index_delta_arith_scaled(uint32_t mag)
 {
+  constexpr uint32_t K = kIdxScale;
   if (BITS == 4) {
-    const uint32_t corr = __builtin_amdgcn_perm(0u, 0x00585450u, mag) & 0xFFu; /* 4 * {20, 21, 22, 0, ...} */
-    return (int32_t)(8u << mag) - (int32_t)corr;
+    const uint32_t corr = __builtin_amdgcn_perm(0u, (22u * K) << 16 | (21u * K) << 8 | (20u * K), mag) & 0xFFu;
+    return (int32_t)((2u * K) << mag) - (int32_t)corr;
   } else if (BITS == 3) {
-    return mag < 2 ? 4 * (int32_t)mag - 64 : (int32_t)(8u << (2u * mag));
+    return mag < 2 ? (int32_t)(K * mag) - (int32_t)(16u * K) : (int32_t)((2u * K) << (2u * mag));
   } else {
-    return mag ? 160 : -56;
+    return mag ? (int32_t)(40u * K) : -(int32_t)(14u * K);
   }
 }
 
@@ -103,14 +105,12 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     if (PACKED) return (k & 1) ? x[k >> 1] >> 16 : (int32_t)(int16_t)x[k >> 1];
     return x[k];
   };
-  /* The step record {2 step, hr, hs} comes from the four-copy wide table with ONE lookup at an address
+  /* The step record {step << 9, hr, hs} comes from the multi-copy wide table with ONE lookup at an address
    * that is one v_and_or_b32 of the scaled step index (see wide4_addr) - the three dense dword arrays
-   * cost two address instructions and three lookups per sample.  Bank conflicts between lanes are the
-   * price (a 96-bit read is served eight lanes per cycle; two lanes with the same copy collide when
-   * their slots have the same parity); with the waves a chip-filling batch keeps on every SIMD that
-   * latency is covered, and the dense mapping is only used for such batches. */
+   * cost two address instructions and three lookups per sample.  With eight copies the eight lanes a
+   * 96-bit read serves per LDS cycle never share a bank (aad_device.hip.h, kWideCopies). */
   int32_t idxj = L.idxb * kIdxScale;
-  const uint32_t copy = (threadIdx.x & 3u) << 4;
+  const uint32_t copy = wide_copy_offset();
   u32x3 e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide4_addr(idxj, copy));
   int32_t p = predict(L);
   int32_t d = sample(0) - p;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     /* A */
     const uint32_t step9 = e.x; /* step << kWideStepShift (stage_tables), 24 bits at most */
     const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)), Pack<BITS>::kMagMax);
-    const int32_t delta = *reinterpret_cast<const int16_t *>(lds + kLdsDelta4Off + (mag << 1)); /* 4 * delta */
+    const int32_t delta = *reinterpret_cast<const int16_t *>(lds + kLdsDeltaScaledOff + (mag << 1)); /* kIdxScale * delta */
     __builtin_amdgcn_sched_barrier(0);
     /* B: (step * (2 mag + 1)) >> (BITS - 1) as ONE high multiply on the 24-bit multiplier, as in the quad body */
     const uint32_t m21s = (mag << (25 - BITS)) | (1u << (24 - BITS));
@@ -160,7 +160,7 @@ __device__ __forceinline__ void encode_chunk16(S &L, const int32_t *x, const cha
     }
     __builtin_amdgcn_sched_barrier(0);
   });
-  L.idxb = idxj >> 2; /* kIdxScale = 4 */
+  L.idxb = idxj >> kIdxScaleLog2;
 }
 
 /*
@@ -176,14 +176,14 @@ struct EncodeCarry {
   int32_t p, d, m; /* its prediction, difference and sign mask */
   float f;         /* (float)d */
   int32_t j;       /* kIdxScale * (biased step index): the chunk bodies' own form of L.idxb */
-  uint32_t copy;   /* this lane's copy of the wide records: 16 * (recurrence slot & 3) */
+  uint32_t copy;   /* byte offset of this lane's copy of the wide records inside a slot (wide_copy_offset) */
 };
 
 template <int BITS>
 __device__ __forceinline__ void encode_prime_quad(QuadLane &L, EncodeCarry &C, int32_t x0, const char *lds)
 {
   C.j = L.idxb * kIdxScale;
-  C.copy = (threadIdx.x & 3u) << 4;
+  C.copy = wide_copy_offset();
   C.e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide4_addr(C.j, C.copy));
   C.p = predict<kEncTM>(L);
   C.d = x0 - C.p;
@@ -238,7 +238,7 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)),
                              Pack<BITS>::kMagMax);
     const uint32_t step9_j = e.x; /* step << kWideStepShift (stage_tables) */
-    idxj = min(max(idxj + index_delta_arith_x4<BITS>(mag), kIdxScale * kIdxMin), kIdxScale * kIdxMax);
+    idxj = min(max(idxj + index_delta_arith_scaled<BITS>(mag), kIdxScale * kIdxMin), kIdxScale * kIdxMax);
     e = *reinterpret_cast<const u32x3 *>(lds + kLdsWideOff + wide4_addr(idxj, copy));
     __builtin_amdgcn_sched_barrier(0);
     /* B: q = (step * (2 mag + 1)) >> (BITS-1) as ONE high multiply on the 24-bit multiplier
@@ -297,7 +297,7 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
   C.m = m;
   C.f = f;
   C.j = idxj;
-  L.idxb = idxj >> 2; /* (kIdxScale = 4) the unscaled form everything outside the chunk bodies uses; dead code unless read */
+  L.idxb = idxj >> kIdxScaleLog2; /* the unscaled form everything outside the chunk bodies uses; dead code unless read */
 }
 
 /* ================================================================================ encode == */

@@ -41,7 +41,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+# VALU issue peak (same guide, "Wave scheduling" + cycle constants; confirmed for the integer, DPP, SDWA and 64-bit
+# multiply-add instructions these kernels use by tools/microbench/ubench_rate.hip, profiles/r03_microbench_valu_rate.txt):
+# a SIMD retires one wave64 vector instruction per 2 cycles once two or more waves share it; ONE wave alone gets an
+# issue slot every ~4 cycles.  256 CUs x 4 SIMDs at 2.4 GHz.
+SIMDS, CLOCK_GHZ, CYCLES_PER_VALU_INST, LONE_WAVE_CYCLES_PER_INST = 1024, 2.4, 2.0, 4.0
+VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / CYCLES_PER_VALU_INST  # G wave-instructions / s
+STAMP_FILE = os.path.join(ROOT, "profiles", "r03_pmc_stamp.json")
 
 
 def kernel_source_digest():
@@ -56,21 +62,67 @@ def kernel_source_digest():
     return h.hexdigest()
 
 
-def measured_traffic(kernel_key, streams, samples):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (made by tools/hbm_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this command line).
-    -> (bytes or None, note).  None when the file does not cover this workload OR was taken from
-    different kernel sources than the ones this run was built from: a stale number is worse than none."""
+def pmc_stamp(workload, role, streams, samples):
+    """Counters per launch of the `role` ("encode" / "decode") kernel of `workload` ("headline" / "saturated") from
+    the committed rocprofv3 --pmc passes (tools/collect_profiles.sh -> tools/stamp_pmc.py).  -> (dict or None, note).
+    None when the file does not cover this workload OR was taken from different kernel sources than the ones this
+    run was built from: a stale number is worse than none."""
     try:
-        t = json.load(open(TRAFFIC_FILE))
+        t = json.load(open(STAMP_FILE))
     except Exception:
-        return None, "no committed PMC traffic measurement"
-    if t.get("streams") != streams or t.get("samples_per_channel") != samples:
-        return None, "committed PMC traffic measurement is for another workload"
+        return None, "no committed PMC measurement"
+    w = t.get("workloads", {}).get(workload)
+    if not w or w.get("streams") != streams or w.get("samples_per_channel") != samples:
+        return None, "the committed PMC measurement is for another workload"
     if t.get("kernel_source_sha256") != kernel_source_digest():
-        return None, "kernel sources changed since the committed PMC passes (%s): re-run tools/collect_profiles.sh" % os.path.basename(TRAFFIC_FILE)
-    k = t.get("kernels", {}).get(kernel_key)
-    return (k.get("hbm_bytes_per_launch"), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, %s" % os.path.basename(TRAFFIC_FILE)) if k else (None, "kernel missing from the PMC file")
+        return None, "kernel sources changed since the committed PMC passes (%s): re-run tools/collect_profiles.sh" % os.path.basename(STAMP_FILE)
+    k = w.get("kernels", {}).get(role)
+    return (k, "rocprofv3 --pmc, separate passes, %s" % os.path.basename(STAMP_FILE)) if k else (None, "kernel missing from the PMC file")
+
+
+def traffic_fields(stamp, note, algorithmic):
+    """roofline.traffic = FETCH_SIZE x 2 + WRITE_SIZE (the guide's gfx950 correction for 16-B-per-lane streams), the
+    raw counter sum beside it.  A corrected figure below 0.95 x the algorithmic bytes cannot be right (every
+    algorithmic byte has to cross the memory interface at least once): it is withheld, not printed."""
+    if not stamp or "hbm_bytes_per_launch" not in stamp:
+        return {"traffic": None, "traffic_raw": None, "traffic_source": note}
+    t, raw = stamp["hbm_bytes_per_launch"], stamp["hbm_bytes_per_launch_raw"]
+    if t < 0.95 * algorithmic:
+        return {"traffic": None, "traffic_raw": raw, "traffic_withheld": t,
+                "traffic_source": note + "; corrected traffic below 0.95 x algorithmic bytes: withheld"}
+    return {"traffic": t, "traffic_raw": raw, "traffic_over_algorithmic": round(t / algorithmic, 3),
+            "traffic_read_x2": stamp.get("read_bytes_x2"), "traffic_write": stamp.get("write_bytes"),
+            "traffic_source": note + ": FETCH_SIZE x 2 + WRITE_SIZE (MI355X_MICROARCH.md, HBM: FETCH_SIZE tallies 64 B per "
+                                     "128-B request); traffic_raw = FETCH_SIZE + WRITE_SIZE as counted"}
+
+
+def valu_fields(stamp, note, kernel_ms, samples_per_recurrence):
+    """The bound that actually applies (SURVEY.md section 8d "state both"): wave-instructions per second against
+    what the chip's 1024 SIMDs can issue.  Instruction counts from the stamped PMC pass (SQ_INSTS_VALU,
+    SQ_WAVES), the duration is THIS run's (HIP events)."""
+    if not stamp or "SQ_INSTS_VALU" not in stamp or not stamp.get("SQ_WAVES"):
+        return {"frac": None, "source": note}
+    insts, waves = stamp["SQ_INSTS_VALU"], stamp["SQ_WAVES"]
+    rate = insts / (kernel_ms * 1e-3) / 1e9  # G wave-instructions / s
+    occupied = min(waves, SIMDS)
+    v = {"insts_per_launch": int(insts), "waves": int(waves),
+         # wave-instructions a recurrence's wave issues per sample of the chain it walks (whole kernel: headers, tails,
+         # loads and stores included)
+         "insts_per_sample": round(insts / waves / samples_per_recurrence, 2),
+         "insts_per_wave": round(insts / waves, 1),
+         "wave_insts_per_s": round(rate * 1e9, 1), "peak_wave_insts_per_s": VALU_PEAK_GINST * 1e9,
+         "cycles_per_inst_assumed": CYCLES_PER_VALU_INST, "clock_ghz_assumed": CLOCK_GHZ,
+         "frac": round(rate / VALU_PEAK_GINST, 5), "source": note + " (SQ_INSTS_VALU, SQ_WAVES); duration from this run"}
+    if waves <= SIMDS:
+        # fewer waves than SIMDs: each wave is alone on its SIMD and is offered an issue slot every ~4 cycles
+        lone_peak = occupied * CLOCK_GHZ / LONE_WAVE_CYCLES_PER_INST
+        v["occupied_simds"] = int(occupied)
+        v["lone_wave_issue_frac"] = round(rate / lone_peak, 4)
+        v["lone_wave_note"] = ("%d waves on %d SIMDs: a wave alone on its SIMD issues at most one instruction per ~%.0f cycles, so "
+                               "this launch can use at most %.3f of the chip's VALU peak; lone_wave_issue_frac is the share of "
+                               "THOSE slots it fills" % (waves, SIMDS, LONE_WAVE_CYCLES_PER_INST,
+                                                         lone_peak / VALU_PEAK_GINST))
+    return v
 
 
 def algorithmic_bytes_per_sample(channels, block_size, spb):
@@ -78,7 +130,8 @@ def algorithmic_bytes_per_sample(channels, block_size, spb):
     return 2.0 + block_size / float(spb * channels)
 
 
-def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1, keep=False, decode_engine=None):
+def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1, keep=False, decode_engine=None,
+            repeats=1, min_timed_s=0.0, max_repeats=1, collective=False):
     """-> dict with wall ms/step (max over ranks) and mean kernel durations from HIP events.
 
     decode_engine: a second context (its own stream) -> the step is PIPELINED: the encode of step k+1
@@ -122,25 +175,39 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
     # record is a packet on the stream; bracketing every step would add ~2 % to a 100 us step)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] if k % event_every == 0 else None
            for k in range(steps)]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        step(evs[k])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:  # MAX over ranks
-        t = torch.tensor([dt], dtype=torch.float64, device=pcm.device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     timed = [e for e in evs if e is not None]
-    enc_ms = sum(e[0].elapsed_time(e[1]) for e in timed) / len(timed)
-    dec_ms = sum(e[2].elapsed_time(e[3]) for e in timed) / len(timed)
+    group = world > 1 or collective  # barriers and the MAX over ranks run whenever a process group is up
+    regions, enc_sum, dec_sum, n_ev = [], 0.0, 0.0, 0
+    # The K-step region is timed `repeats` times over (at least; more while less than `min_timed_s` of
+    # timed work has accumulated, up to `max_repeats`): one region of the headline batch is ~1.5 ms at the
+    # driver's K = 20, and a single such window moved by 6 % between two runs of the same build.
+    # Every region is exactly K steps between barrier + synchronize on both sides; the line reports the
+    # median region.  The stop rule uses the MAX-over-ranks times, so every rank runs the same count.
+    while len(regions) < repeats or (sum(regions) < min_timed_s and len(regions) < max_repeats):
+        torch.cuda.synchronize()
+        if group:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(evs[k])
+        torch.cuda.synchronize()
+        if group:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if group:  # MAX over ranks
+            t = torch.tensor([dt], dtype=torch.float64, device=pcm.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        regions.append(dt)
+        enc_sum += sum(e[0].elapsed_time(e[1]) for e in timed)
+        dec_sum += sum(e[2].elapsed_time(e[3]) for e in timed)
+        n_ev += len(timed)
+    ordered = sorted(regions)
+    dt = ordered[len(ordered) // 2] if len(ordered) % 2 else 0.5 * (ordered[len(ordered) // 2 - 1] + ordered[len(ordered) // 2])
+    enc_ms, dec_ms = enc_sum / n_ev, dec_sum / n_ev
     ok = bool((out == pcm).float().mean() > 0.0)  # touch the result so nothing is elided
-    res = dict(wall_s=dt, enc_ms=enc_ms, dec_ms=dec_ms, header=header, touched=ok, image_size=image_size)
+    res = dict(wall_s=dt, wall_min_s=ordered[0], wall_max_s=ordered[-1], regions=len(regions), timed_s=sum(regions),
+               enc_ms=enc_ms, dec_ms=dec_ms, header=header, touched=ok, image_size=image_size)
     if keep:  # what the LAST timed step left in HBM, for the bit-exact flags
         res["img"] = last[0][:, :image_size].contiguous().cpu().numpy()
         res["out"] = out.cpu().numpy()
@@ -415,7 +482,7 @@ def config_entry(engine, torch, dist, name, streams, samples, ch, bits, trials, 
                 bit_exact_vs_reference_golden=flag)
 
 
-def config5_batched_files(engine, torch, dist, rank, world, files_per_rank=1250, blocks=10):
+def config5_batched_files(engine, torch, dist, rank, world, files_per_rank=1250, blocks=10, force_collectives=False):
     """BASELINE config 5: one rank owns the job table; RCCL broadcast of the
     table, every rank encodes its files device-resident (its own reader: the corpus streams it was
     dealt), RCCL gather of the image rows to rank 0, which hashes them in job order against the
@@ -426,7 +493,8 @@ def config5_batched_files(engine, torch, dist, rank, world, files_per_rank=1250,
     param = make_parameter(2, 4, 1024, 48000, False, 0)
     samples = 992 * blocks
     total = files_per_rank * world
-    codec = BatchCodec(rank=rank, world=world, dist=dist, device="cuda:%d" % engine.device, engine=engine)
+    codec = BatchCodec(rank=rank, world=world, dist=dist, device="cuda:%d" % engine.device, engine=engine,
+                       force_collectives=force_collectives)
 
     def shard_pcm(indices):  # this rank's "files": corpus streams `indices`
         parts = [synth_pcm(1, samples, 2, seed=1234, first_stream=i)[0] for i in indices]
@@ -489,6 +557,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--serial", action="store_true", help="do not overlap the encode of step k+1 with the decode of step k")
     ap.add_argument("--event-every", type=int, default=8, help="bracket the kernels with HIP events on every n-th timed step")
+    ap.add_argument("--repeats", type=int, default=9, help="time the K-step region at least this many times; the line reports the median region")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="...and until this much timed work has accumulated (at most 101 regions)")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="N = 1: skip the batched-file leg under a one-rank RCCL group (BASELINE config 5's code path with the collectives forced)")
     args = ap.parse_args()
 
     import numpy as np  # noqa: F401
@@ -528,14 +600,16 @@ def main():
     # carries that figure too (`serial`).
     decode_engine = None if args.serial else Engine(local, stream=torch.cuda.Stream(local))  # a stream of its own, not torch's current one
     m = measure(engine, torch, dist, pcm, param, args.steps, args.warmup, world, args.event_every, keep=(rank == 0),
-                decode_engine=decode_engine)
+                decode_engine=decode_engine, repeats=args.repeats, min_timed_s=args.min_timed_ms * 1e-3, max_repeats=max(args.repeats, 101))
     hd = m["header"]
     n_step = args.streams * samples * ch  # channel-samples per direction per rank
-    value = 2.0 * n_step * world * args.steps / m["wall_s"] / 1e6
+    value = 2.0 * n_step * world * args.steps / m["wall_s"] / 1e6  # the MEDIAN K-step region
     bps = algorithmic_bytes_per_sample(ch, hd.block_size, hd.num_samples_per_block)
     enc_gbs = n_step * bps / (m["enc_ms"] * 1e-3) / 1e9
     dec_gbs = n_step * bps / (m["dec_ms"] * 1e-3) / 1e9
-    traffic, traffic_note = measured_traffic("encode", args.streams, samples)
+    stamp_e, note_e = pmc_stamp("headline", "encode", args.streams, samples)
+    stamp_d, note_d = pmc_stamp("headline", "decode", args.streams, samples)
+    algorithmic = int(round(n_step * bps))
     quad_note = "auto (quad for this batch size: four lanes per recurrence; decode with the step-index walk as a parallel scan)"
 
     line = {
@@ -546,6 +620,12 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(m["wall_s"] / args.steps * 1e3, 5),
+        "value_min": round(2.0 * n_step * world * args.steps / m["wall_max_s"] / 1e6, 3),
+        "value_max": round(2.0 * n_step * world * args.steps / m["wall_min_s"] / 1e6, 3),
+        "timed_regions": {"count": m["regions"], "steps_each": args.steps, "timed_s": round(m["timed_s"], 6),
+                          "rule": "the K-step region (barrier + synchronize on both sides) is timed at least %d times and until "
+                                  "%.0f ms of timed work; value / ms_per_step are the MEDIAN region, value_min / value_max the "
+                                  "slowest / fastest" % (args.repeats, args.min_timed_ms)},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -568,23 +648,30 @@ def main():
         "bit_exact_vs_reference_golden": golden_check(m, args.streams, samples, ch, bits, args.trials) if rank == 0 else None,
         "encode_msps": round(n_step * world / (m["enc_ms"] * 1e-3) / 1e6, 3),
         "decode_msps": round(n_step * world / (m["dec_ms"] * 1e-3) / 1e6, 3),
-        "roofline": {
-            "kernel": "aad::encode_streams_kernel<4>",
-            "bound": "hbm", "achieved": round(enc_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(enc_gbs / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_note,
-            "algorithmic_bytes_per_launch": int(round(n_step * bps)),
-            "bytes_per_sample": round(bps, 4), "samples_per_launch": n_step,
-            "kernel_ms": round(m["enc_ms"], 5), "hip_events": "on every %d-th step of the timed region" % args.event_every,
-            "decode_kernel": {"kernel": "aad::decode_split_kernel<4> (quad batches) / aad::decode_blocks_kernel<4> (dense)", "achieved": round(dec_gbs, 3),
-                              "frac": round(dec_gbs / HBM_PEAK_GBS, 6), "kernel_ms": round(m["dec_ms"], 5)},
-            "note": "a 2000-recurrence batch is bound by per-wave instruction issue, not by bandwidth (DESIGN.md \"Kernels\"); "
-                    "`saturated` shows the same kernels on a chip-filling batch",
-        },
+        "roofline": dict(
+            {"kernel": (stamp_e or {}).get("kernel", "aad::encode_streams_kernel<4, 2, ...>"),
+             "bound": "hbm", "achieved": round(enc_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(enc_gbs / HBM_PEAK_GBS, 6)},
+            **traffic_fields(stamp_e, note_e, algorithmic),
+            **{"algorithmic_bytes_per_launch": algorithmic,
+               "bytes_per_sample": round(bps, 4), "samples_per_launch": n_step,
+               "kernel_ms": round(m["enc_ms"], 5),
+               "kernel_ms_note": "HIP events on the encode stream, on every %d-th step of the timed regions; PIPELINED run: the decode "
+                                 "of the previous step occupies the other half of the chip meanwhile (`serial.encode_kernel_ms` is the "
+                                 "same kernel with the chip to itself)" % args.event_every if not args.serial else
+                                 "HIP events on the launch stream, on every %d-th step of the timed regions" % args.event_every,
+               "valu": valu_fields(stamp_e, note_e, m["enc_ms"], samples),
+               "decode_kernel": dict({"kernel": (stamp_d or {}).get("kernel", "aad::decode_split_kernel<4> (quad batches) / aad::decode_blocks_kernel<4> (dense)"),
+                                      "achieved": round(dec_gbs, 3), "frac": round(dec_gbs / HBM_PEAK_GBS, 6), "kernel_ms": round(m["dec_ms"], 5),
+                                      "valu": valu_fields(stamp_d, note_d, m["dec_ms"], hd.num_samples_per_block)},
+                                     **traffic_fields(stamp_d, note_d, algorithmic)),
+               "note": "a 2000-recurrence batch is bound by per-wave instruction issue, not by bandwidth (DESIGN.md \"Kernels\"): `valu` "
+                       "carries that bound; `saturated` shows the same kernels on a chip-filling batch"}),
     }
 
     if not args.serial:  # the same K steps with nothing overlapped, for reference
         ks = max(10, args.steps // 4)
-        ms_ = measure(engine, torch, dist, pcm, param, ks, min(args.warmup, 3), world, args.event_every)
+        ms_ = measure(engine, torch, dist, pcm, param, ks, min(args.warmup, 3), world, args.event_every, repeats=5, max_repeats=5)
         line["serial"] = {"value": round(2.0 * n_step * world * ks / ms_["wall_s"] / 1e6, 3), "unit": "Msamples/s",
                           "steps": ks, "ms_per_step": round(ms_["wall_s"] / ks * 1e3, 5),
                           "encode_kernel_ms": round(ms_["enc_ms"], 5), "decode_kernel_ms": round(ms_["dec_ms"], 5),
@@ -594,7 +681,7 @@ def main():
     if extras:
         # the reference CLI's default operating point: the same batch with the trial search (src/main.c:45-47)
         p2 = make_parameter(ch, bits, mbs, 48000, False, 2)
-        m2 = measure(engine, torch, dist, pcm, p2, max(10, args.steps // 4), 3, 1, 1, keep=True, decode_engine=decode_engine)
+        m2 = measure(engine, torch, dist, pcm, p2, max(10, args.steps // 4), 3, 1, 1, keep=True, decode_engine=decode_engine, repeats=5, max_repeats=5)
         e2 = n_step * bps / (m2["enc_ms"] * 1e-3) / 1e9
         line["trials2"] = {
             "workload": "the headline batch with num_encode_trials = 2 (reference CLI default, src/main.c:45-47)",
@@ -629,7 +716,13 @@ def main():
             "encode_gbs": round(nb * bps / (ms["enc_ms"] * 1e-3) / 1e9, 2), "decode_gbs": round(nb * bps / (ms["dec_ms"] * 1e-3) / 1e9, 2),
             "encode_frac": round(nb * bps / (ms["enc_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "decode_frac": round(nb * bps / (ms["dec_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "algorithmic_bytes_per_launch": int(round(nb * bps)),
         }
+        for role, kms, per_rec in (("encode", ms["enc_ms"], samples), ("decode", ms["dec_ms"], hd.num_samples_per_block)):
+            st, note = pmc_stamp("saturated", role, big_streams, samples)
+            line["saturated"][role] = dict({"kernel": (st or {}).get("kernel"), "kernel_ms": round(kms, 5)},
+                                           **traffic_fields(st, note, int(round(nb * bps))),
+                                           **{"valu": valu_fields(st, note, kms, per_rec)})
 
         if extras:
             # the other fast-path geometries on chip-filling batches of one-block streams (524 288 recurrences each),
@@ -656,6 +749,31 @@ def main():
         c5 = config5_batched_files(engine, torch, dist, rank, world)
         if rank == 0:
             line["config5"] = c5
+    elif world == 1 and args.blocks == 1 and not args.no_config5:
+        # One GPU: the same leg under a ONE-rank RCCL process group with the collectives forced (a world of one would
+        # skip them), so that the code an N > 1 run depends on - init_process_group(device_id=), broadcast and
+        # gather of device tensors, the float64 all_reduce and the barriers of measure() - executes on this box
+        # too.  A failure to bring RCCL up is reported on the line, it does not take the headline down.
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+            try:
+                c5 = config5_batched_files(engine, torch, dist, 0, 1, force_collectives=True)
+                # the N > 1 timing path of measure() (barriers, MAX all_reduce on a device tensor), a short rehearsal
+                mr = measure(engine, torch, dist, pcm, param, 20, 3, 1, args.event_every, decode_engine=decode_engine,
+                             repeats=3, max_repeats=3, collective=True)
+                c5["collective_timing_rehearsal"] = {
+                    "value": round(2.0 * n_step * 20 / mr["wall_s"] / 1e6, 3), "unit": "Msamples/s", "steps": 20, "regions": mr["regions"],
+                    "note": "the headline step timed the way an N > 1 run times it: dist.barrier() on both sides of every region and "
+                            "the region time MAX-reduced over the (one) rank as a float64 device tensor through RCCL"}
+                c5["world_size"] = 1
+                c5["collectives"] = "forced (BatchCodec(force_collectives=True)): broadcast + gather run through RCCL with one rank"
+                line["config5"] = c5
+            finally:
+                dist.destroy_process_group()
+        except Exception as e:  # noqa: BLE001 - reported, not raised
+            line["config5"] = {"error": repr(e)[:400], "backend": "nccl", "world_size": 1}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         trials_list = [args.trials] + ([2] if extras and args.trials != 2 else [])
