@@ -34,13 +34,15 @@ __device__ __forceinline__ int32_t decode_step(S &L, uint32_t code, const char *
  *   A  step index of the next sample; start its step lookup and the record lookup of sample j+2
  *   B  dequantise (mad + shift), reconstruct, LMS, history shift, predict the next sample
  */
-template <int BITS, int N = kChunk, typename S, typename Finish>
+/* REC8: the per-code records come from the 8-byte table (kLdsDenseCode8Off: conflict-free ds_read_b64, one v_mov_b32 for
+ * the addend's upper word) instead of the 16-byte one */
+template <int BITS, int N = kChunk, bool REC8 = false, typename S, typename Finish>
 __device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const char *lds, int32_t *y, Finish finish)
 {
   static_assert(N >= 2 && N <= kChunk, "the first N samples of a chunk's code words");
   constexpr int cpw = Pack<BITS>::kCodesPerWord;
-  auto code_addr = [&](int j) -> uint32_t { /* (code << 4) for sample j, j compile-time after unrolling */
-    constexpr int sh = 4;
+  auto code_addr = [&](int j) -> uint32_t { /* (code << 4) - or << 3 - for sample j, j compile-time after unrolling */
+    constexpr int sh = REC8 ? 3 : 4;
     const int pos = Pack<BITS>::pos(j % cpw);
     const uint32_t word = w[j / cpw];
     return (pos >= sh ? word >> (pos >= sh ? pos - sh : 0) : word << (sh - pos)) & (((1u << BITS) - 1u) << sh);
@@ -50,7 +52,13 @@ __device__ __forceinline__ void decode_chunk16(S &L, const uint32_t *w, const ch
    * two-instruction address), same box, kernel time in us - 1000 x 16 blocks 66.4 vs 71.2, 1250 x 10
    * blocks 65.2 vs 69.8, 20 000 mono blocks 121 vs 137; at saturation, where the kernel waits for
    * memory, the same (0.60 ms) although the records cost 5 conflict cycles per lookup there */
-  auto record = [&](uint32_t addr) { return *reinterpret_cast<const u32x3 *>(lds + kLdsDenseCodeOff + addr); };
+  auto record = [&](uint32_t addr) -> u32x3 {
+    if (REC8) {
+      const u32x2 r = *reinterpret_cast<const u32x2 *>(lds + kLdsDenseCode8Off + addr);
+      return u32x3{r.x, 0u, r.y};
+    }
+    return *reinterpret_cast<const u32x3 *>(lds + kLdsDenseCodeOff + addr);
+  };
   const uint32_t copy = (threadIdx.x & 3u) << 2;
   auto step_at = [&](int32_t idxb) { return *reinterpret_cast<const uint32_t *>(lds + kLdsDenseStepOff + (((uint32_t)idxb & 0xFF0u) | copy)); };
   uint32_t step = step_at(L.idxb); /* step << 2 */
@@ -193,7 +201,7 @@ struct DecodeArgs {
   uint32_t mid_side;
   uint32_t bits;
   uint32_t stream_stores; /* dense stereo kernel: every chunk store of every block is a whole 64-byte granule (host-checked): launch the NT instantiation */
-  uint32_t reserved;
+  uint32_t pcm_aligned16; /* every stream's PCM starts on a 16-byte boundary relative to `pcm` (host-checked): what the sector-tiled kernel needs */
   UniformLayout uni;
 };
 

@@ -1,0 +1,40 @@
+/*
+ * aad_decode_tiled.hip - translation unit of the sector-tiled dense decoder (aad_decode_tiled.hip.h).
+ */
+#include "aad_decode_tiled.hip.h"
+#include "aad_decode_tiled_launch.h"
+
+namespace aad {
+
+bool decode_tiled_applicable(const DecodeArgs &a)
+{
+  if (a.channels < 1 || a.channels > 2) return false;
+  if (a.bits != 4 && a.bits != 2) return false;
+  if (!a.pcm_aligned16) return false;
+  if (((uint64_t)a.samples_per_block * a.channels * 2u) % 16u != 0) return false; /* every block of a stream starts on a piece boundary */
+  if ((reinterpret_cast<uintptr_t>(a.pcm) & 15u) != 0) return false;
+  return true;
+}
+
+template <int BITS>
+static void launch_bits(const DecodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
+{
+  if (a.channels == 1)
+    hipLaunchKernelGGL((decode_tiled_kernel<BITS, 1, false>), grid, block, 0, stream, a);
+  else if (a.mid_side)
+    hipLaunchKernelGGL((decode_tiled_kernel<BITS, 2, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((decode_tiled_kernel<BITS, 2, false>), grid, block, 0, stream, a);
+}
+
+bool launch_decode_tiled(const DecodeArgs &a, hipStream_t stream)
+{
+  if (!decode_tiled_applicable(a)) return false;
+  const uint64_t lanes = a.total_blocks * a.channels;
+  const dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
+  if (a.bits == 4) launch_bits<4>(a, grid, block, stream);
+  else launch_bits<2>(a, grid, block, stream);
+  return true;
+}
+
+} /* namespace aad */

@@ -1,0 +1,398 @@
+/*
+ * aad_decode_tiled.hip.h - the dense decoder with SECTOR-TILED I/O (reference src/aad_decoder.c:321-475,
+ * the same arithmetic as decode_blocks_kernel: lane = (block, channel), decode_chunk16 per 16 samples).
+ *
+ * Why: in the dense mapping the lanes of a wave are a whole block apart in memory, so when every lane moves
+ * its own bytes a wave-level load or store touches 64 different 128-byte lines for 16 bytes each.  Measured
+ * on a chip-filling batch (profiles/r03a_saturated_geometries_pmc.txt, tools/microbench/ubench_fetch.hip):
+ *   - a read that misses the L2 always fills a whole 128-byte line; a lane that walks its line in 64-byte
+ *     bursts a chunk-group's worth of time apart fetches it twice - three times when the bursts straddle
+ *     (code bytes start 49 / 67 bytes into an image): the mono decoder moved 3.5x its code bytes;
+ *   - the same pattern moves 3.7-4.5 TB/s where rows of adjacent lanes move 4.9-5.3 TB/s;
+ *   - the kernel's VALU sat idle 26-41 % of the time waiting for those lines.
+ * Here the memory side of a wave works on ROWS instead: a row is one block (mono: one lane, stereo: the
+ * lane pair), and a wave-level access covers whole aligned granules of a row with ADJACENT lanes -
+ * mono: 4 lanes x 16 B = one 64-byte sector of each of 16 rows per instruction, stereo: 8 lanes x 16 B =
+ * one 128-byte line of each of 8 rows.  The granules pass through a two-granule ring per row in LDS:
+ *   in   code bytes: cooperative global_load -> ds_write_b128 into the row's ring; the row's lane(s) read
+ *        their chunk's bytes back as aligned dwords (a granule is sector-aligned in MEMORY, the chunk's bytes
+ *        sit at the byte phase the .aad layout gives them - one v_perm_b32 selector per lane absorbs it);
+ *        the block header comes through the ring as well (18 byte loads per lane less);
+ *   out  PCM: the lanes write their packed chunks (ds_write_b128) at the row's phase; after every second
+ *        chunk the oldest granule of every row is complete and leaves with one cooperative store
+ *        (ds_read_b128 -> global_store_dwordx4), 16-byte pieces outside a row's range masked.
+ * Every granule is fetched once and written once, as whole sectors / lines, two periods ahead of its use
+ * (memory latency never meets the recurrence), with a quarter of the L2 requests.  LDS: 272 (mono) or 528
+ * (stereo) bytes per row = 17 KB per wave, so a CU holds 8 waves (two per SIMD) - enough, because what
+ * is left to wait for is LDS, and the chunk body was software-pipelined for a lone wave.
+ *
+ * Scope: 4- and 2-bit codes (a 3-bit chunk is 6 bytes, which divides no granule: those streams keep the
+ * per-lane kernel), mono / stereo, every block's PCM 16-byte aligned (host-checked: uniform batches are).
+ * Blocks shorter than a chunk, truncated images and the last samples of a block take the same per-lane
+ * tail as decode_blocks_kernel; both kernels produce identical bytes (tests run them side by side).
+ */
+#ifndef AAD_DECODE_TILED_HIP_H
+#define AAD_DECODE_TILED_HIP_H
+
+#include "aad_decode.hip.h"
+
+namespace aad {
+
+template <int BITS, int CHF>
+struct DecodeTile {
+  static_assert((BITS == 4 || BITS == 2) && (CHF == 1 || CHF == 2), "4- / 2-bit codes, mono / stereo");
+  static constexpr int kRows = 64 / CHF;                       /* rows (blocks) per wave */
+  static constexpr int kG = CHF == 1 ? 64 : 128;               /* granule bytes, both directions */
+  static constexpr int kGLog2 = CHF == 1 ? 6 : 7;
+  static constexpr int kRing = 2 * kG;                         /* two granules per row and direction */
+  static constexpr int kMirror = 16;                           /* the input ring's first 16 bytes again behind its end: a chunk's aligned dwords never wrap */
+  /* the output ring carries 16 bytes of padding: rows a multiple of 128 bytes apart put the same piece of every row on
+   * the same banks (an eight-way conflict on every ds_write_b128 of packed PCM) */
+  static constexpr int kInPitch = kRing + kMirror, kOutPitch = kRing + 16;
+  static constexpr int kCb = Pack<BITS>::kChunkBytes * CHF;    /* code bytes of a row per chunk: 8 / 16 (4-bit), 4 / 8 (2-bit) */
+  static constexpr int kInPeriod = kG / kCb;                   /* chunks per input granule: 8 (4-bit), 16 (2-bit) */
+  static constexpr int kPcmBytes = 2 * kChunk * CHF;           /* PCM bytes of a row per chunk: 32 / 64 */
+  static_assert(kG / kPcmBytes == 2, "an output granule is two chunks");
+  static constexpr int kLead = 12;                             /* decoded samples of the lead chunk (+ 4 verbatim) */
+  static constexpr int kLeadBytes = kLead * BITS / 8 * CHF;
+  static constexpr int kLanesPerRow = kG / 16;                 /* lanes that cover one granule: 4 / 8 */
+  static constexpr int kRowsPerInst = 64 / kLanesPerRow;       /* 16 / 8 */
+  static constexpr int kInst = kRows / kRowsPerInst;           /* wave-level accesses per granule of every row: 4 */
+  static constexpr int kMetaBytes = 32;                        /* per row, see RowMeta */
+  /* the row records are read once, before the first PCM byte is written: they lie in the output rings' space */
+  static constexpr int kInOff = 0, kOutOff = kRows * kInPitch, kMetaOff = kOutOff;
+  static constexpr int kWaveBytes = kOutOff + kRows * kOutPitch;
+  static_assert(kMetaBytes <= kOutPitch, "a row's record fits its own output ring");
+};
+
+/* what the lanes that move a row's granules need to know about it (written by the row's channel-0 lane) */
+struct RowMeta {
+  uint64_t in_base;  /* address of input granule 0: the aligned granule that holds the first code byte behind the lead chunk */
+  int32_t g_min, g_max; /* granules of this row that hold at least one byte of the block (loads are clamped to them) */
+  uint64_t out_base; /* address of output granule 0: the aligned granule that holds the block's first PCM byte */
+  uint32_t lo, hi;   /* bytes of the row's PCM that come out of the ring, relative to out_base (multiples of 16) */
+};
+static_assert(sizeof(RowMeta) == 32, "RowMeta is one 32-byte LDS record");
+
+constexpr int kLdsTileOff = (kLdsBytesDenseDec + 15) & ~15;
+
+/* the compiler sees one thread: tell it that LDS written here is read by OTHER lanes of the wave (no instruction:
+ * the LDS serves a wave's accesses in order) */
+__device__ __forceinline__ void wave_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+/* A 16-byte store that does not stay in the L2 (sc1: write-through, the line is dropped - MI355X_MICROARCH.md, "stores of
+ * each flavour").  The PCM is written once and never read back; kept in the L2 it evicts the code lines, whose second
+ * sector a mono row comes back for one period later (measured: with plain stores every sector visit was a line fill of
+ * its own - FETCH_SIZE x 2 = 2.0x the code bytes - and the half-written PCM lines left the L2 as 1.27x their bytes). */
+#ifndef AAD_TILED_STORE_SC1
+#define AAD_TILED_STORE_SC1 1
+#endif
+__device__ __forceinline__ void store_through(uint64_t address, const u32x4 &v)
+{
+#if AAD_TILED_STORE_SC1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(address), "v"(v) : "memory");
+#else
+  *reinterpret_cast<u32x4 *>(address) = v;
+#endif
+}
+
+template <int BITS, int CHF, bool MS>
+__global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
+{
+  using T = DecodeTile<BITS, CHF>;
+  constexpr uint32_t ch = CHF;
+  constexpr uint32_t kRingMask = T::kRing - 1;
+  __shared__ __attribute__((aligned(16))) char lds[kLdsTileOff + 4 * T::kWaveBytes];
+  stage_tables<BITS, false>(lds);
+  stage_dense_decode_tables<BITS>(lds);
+
+  const uint32_t wl = threadIdx.x & 63u; /* lane within the wave */
+  char *const tile = lds + kLdsTileOff + (threadIdx.x >> 6) * T::kWaveBytes;
+  const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; /* index of the (block, channel) recurrence */
+  const uint64_t wave_first = lane - wl;
+  if (wave_first >= a.total_blocks * ch) return; /* the whole wave: nothing to decode, nothing to move */
+  const bool active = lane < a.total_blocks * ch;
+  const uint64_t g = active ? lane / ch : 0;
+  const uint32_t c = active ? (uint32_t)(lane % ch) : 0;
+  const uint32_t my_row = wl / CHF;
+
+  /* ---- this lane's block, exactly as decode_blocks_kernel finds it */
+  uint32_t s;
+  StreamDesc sd;
+  uint64_t b;
+  if (a.uni.enabled) {
+    s = (uint32_t)g / a.uni.blocks_per_stream;
+    b = (uint32_t)g - s * a.uni.blocks_per_stream;
+    sd = uniform_stream(a.uni, s);
+  } else {
+    s = find_stream(a.block_prefix, a.num_streams, g);
+    sd = a.streams[s];
+    b = g - a.block_prefix[s];
+  }
+  const uint64_t first = b * a.samples_per_block;
+  uint32_t n = 0;
+  if (active && first < sd.num_samples) {
+    const uint64_t left = sd.num_samples - first;
+    n = left < a.samples_per_block ? (uint32_t)left : a.samples_per_block;
+  }
+  const uint64_t block_off = a.header_bytes + b * a.block_size;
+  const uint64_t avail64 = sd.data_size > block_off ? sd.data_size - block_off : 0;
+  const uint32_t avail = avail64 > 0x7FFFFFFFu ? 0x7FFFFFFFu : (uint32_t)avail64;
+  const uint8_t *src = a.data + sd.data_offset + block_off;
+  int16_t *dst = a.pcm + sd.pcm_offset + first * ch + c;
+  constexpr uint32_t body = (uint32_t)kBlockHeaderBytesPerCh * ch;
+  if (avail < body) n = 0;
+
+  constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
+  const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
+  const bool lead = coded >= (uint32_t)T::kLead && avail >= body + T::kLeadBytes;
+  uint32_t full = 0; /* whole 16-sample chunks behind the lead chunk whose code bytes are all there */
+  if (lead) {
+    full = (coded - T::kLead) / kChunk;
+    const uint32_t fit = (avail - body - T::kLeadBytes) / T::kCb;
+    full = full < fit ? full : fit;
+  }
+
+  /* ---- the row's place in memory, published for the lanes that move its granules */
+  const uintptr_t code0 = reinterpret_cast<uintptr_t>(src) + body + T::kLeadBytes; /* first code byte behind the lead chunk */
+  const uintptr_t in_base = code0 & ~(uintptr_t)(T::kG - 1);
+  const int32_t hdr_pos = (int32_t)(reinterpret_cast<uintptr_t>(src) - in_base); /* block start relative to granule 0 (<= 0 ... < kG) */
+  const uintptr_t pcm0 = reinterpret_cast<uintptr_t>(a.pcm + sd.pcm_offset + first * ch);
+  const uintptr_t out_base = pcm0 & ~(uintptr_t)(T::kG - 1);
+  const uint32_t theta = (uint32_t)(pcm0 - out_base); /* a multiple of 16: the host only launches this kernel on such layouts */
+  if (c == 0) {
+    RowMeta m;
+    m.in_base = in_base;
+    const uint32_t present = avail < a.block_size ? avail : a.block_size; /* bytes of this block that exist */
+    m.g_min = hdr_pos >> T::kGLog2;                                        /* floor: -1 or 0 */
+    m.g_max = n ? (int32_t)((uint32_t)(hdr_pos + (int32_t)present - 1 + T::kG) >> T::kGLog2) - 1 : m.g_min;
+    if (m.g_max < m.g_min) m.g_max = m.g_min;
+    m.out_base = out_base;
+    m.lo = theta;
+    m.hi = theta + (lead ? (1u + full) * T::kPcmBytes : 0u);
+    *reinterpret_cast<RowMeta *>(tile + T::kMetaOff + my_row * T::kMetaBytes) = m;
+  }
+  /* trip count of the wave: the longest row's */
+  uint32_t full_max = full;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)full_max, o, 64);
+    full_max = other > full_max ? other : full_max;
+  }
+  full_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)full_max);
+  wave_lds_fence();
+
+  /* ---- the rows this lane moves: instruction i covers rows i * kRowsPerInst + wl / kLanesPerRow, piece wl % kLanesPerRow */
+  const uint32_t piece = wl % T::kLanesPerRow, sub_row = wl / T::kLanesPerRow;
+  uint64_t mv_in[T::kInst], mv_out[T::kInst];
+  int32_t mv_gmin[T::kInst], mv_gmax[T::kInst];
+  uint32_t mv_lo[T::kInst], mv_hi[T::kInst];
+#pragma unroll
+  for (int i = 0; i < T::kInst; i++) {
+    const RowMeta m = *reinterpret_cast<const RowMeta *>(tile + T::kMetaOff + (i * T::kRowsPerInst + sub_row) * T::kMetaBytes);
+    mv_in[i] = m.in_base + 16u * piece;
+    mv_out[i] = m.out_base + 16u * piece;
+    mv_gmin[i] = m.g_min;
+    mv_gmax[i] = m.g_max;
+    mv_lo[i] = m.lo;
+    mv_hi[i] = m.hi;
+  }
+  /* cooperative moves.  Rows of inactive lanes (the tail of the last wave) were never published: their metadata is
+   * whatever the LDS held - so those lanes publish too (c == 0 above covers them: g = 0, n = 0, hi = lo). */
+  auto load_granule = [&](int32_t v, u32x4 (&r)[T::kInst]) {
+#pragma unroll
+    for (int i = 0; i < T::kInst; i++) {
+      const int32_t gv = min(max(v, mv_gmin[i]), mv_gmax[i]);
+      r[i] = *reinterpret_cast<const u32x4 *>(mv_in[i] + ((int64_t)gv << T::kGLog2));
+    }
+  };
+  auto put_granule = [&](int32_t v, const u32x4 (&r)[T::kInst]) {
+    const uint32_t slot = ((uint32_t)v & 1u) * T::kG + 16u * piece;
+#pragma unroll
+    for (int i = 0; i < T::kInst; i++) {
+      char *ring = tile + T::kInOff + (i * T::kRowsPerInst + sub_row) * T::kInPitch;
+      *reinterpret_cast<u32x4 *>(ring + slot) = r[i];
+      if (slot == 0) *reinterpret_cast<u32x4 *>(ring + T::kRing) = r[i]; /* the mirror of the ring's first 16 bytes */
+    }
+  };
+  auto read_granule = [&](uint32_t t, u32x4 (&r)[T::kInst]) { /* this lane's pieces of output granule t, out of the rows' rings */
+    const uint32_t slot = (t & 1u) * T::kG + 16u * piece;
+#pragma unroll
+    for (int i = 0; i < T::kInst; i++)
+      r[i] = *reinterpret_cast<const u32x4 *>(tile + T::kOutOff + (i * T::kRowsPerInst + sub_row) * T::kOutPitch + slot);
+  };
+  auto write_granule = [&](uint32_t t, const u32x4 (&r)[T::kInst]) { /* ... to memory, the pieces that belong to their row */
+    const uint32_t at = t * T::kG + 16u * piece;
+#pragma unroll
+    for (int i = 0; i < T::kInst; i++)
+      if (at >= mv_lo[i] && at < mv_hi[i]) store_through(mv_out[i] + (uint64_t)t * T::kG, r[i]);
+  };
+
+  /* ---- prologue: granules -1 and 0 (block header, lead chunk, first codes) and granule 1 */
+  u32x4 ga[T::kInst], gb[T::kInst], gn[T::kInst];
+  load_granule(-1, ga);
+  load_granule(0, gb);
+  load_granule(1, gn);
+  put_granule(-1, ga);
+  put_granule(0, gb);
+  wave_lds_fence();
+
+  const char *const in_ring = tile + T::kInOff + my_row * T::kInPitch;
+  char *const out_ring = tile + T::kOutOff + my_row * T::kOutPitch;
+  auto ring_byte = [&](int32_t pos) -> uint32_t { return (uint32_t)(uint8_t)in_ring[(uint32_t)pos & kRingMask]; };
+  auto ring_be16 = [&](int32_t pos) -> uint32_t { return (ring_byte(pos) << 8) | ring_byte(pos + 1); };
+
+  Lane H = {0, 0, 0, 0, 0, 0, 0, 0, kIdxBias};
+  if (n) { /* block header - reference src/aad_decoder.c:364-380 */
+    const int32_t hp = hdr_pos + (int32_t)(c * kBlockHeaderBytesPerCh);
+    const uint32_t v = ring_be16(hp);
+    H.idxb = min((int32_t)(v >> 4), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias;
+    const uint32_t shift = v & 0xFu;
+    H.w0 = (int32_t)((uint32_t)(int32_t)(int16_t)ring_be16(hp + 2) << shift);
+    H.h0 = (int16_t)ring_be16(hp + 4);
+    H.w1 = (int32_t)((uint32_t)(int32_t)(int16_t)ring_be16(hp + 6) << shift);
+    H.h1 = (int16_t)ring_be16(hp + 8);
+    H.w2 = (int32_t)((uint32_t)(int32_t)(int16_t)ring_be16(hp + 10) << shift);
+    H.h2 = (int16_t)ring_be16(hp + 12);
+    H.w3 = (int32_t)((uint32_t)(int32_t)(int16_t)ring_be16(hp + 14) << shift);
+    H.h3 = (int16_t)ring_be16(hp + 16);
+  }
+  auto finish = [&](int32_t y) -> int32_t {
+    if (MS) {
+      const int32_t other = (int32_t)pair_swap<false>((uint32_t)y, c);
+      return c == 0 ? clip16(y + other) : clip16(other - y);
+    }
+    return y;
+  };
+  const int32_t y0 = finish(H.h3), y1 = finish(H.h2), y2 = finish(H.h1), y3 = finish(H.h0);
+  Lane L = H;
+
+  /* The code bytes of the chunk whose first byte is `pos` bytes from granule 0 (negative: the lead chunk), read as
+   * aligned dwords (`raw`: the ring's mirror lets them run past its end) one chunk AHEAD of their use, and the
+   * chunk's big-endian code words from them.  The byte phase pos & 3 is absorbed by the selector of a v_perm_b32
+   * (mono) or by v_alignbyte_b32 (stereo: the pair's L/R-interleaved bytes are realigned, then this channel's
+   * picked); it is the same for every chunk of a block (a chunk is 4 .. 16 bytes). */
+  constexpr int kRaw = T::kCb / 4 + 1;
+  auto fetch_raw = [&](int32_t pos, uint32_t (&raw)[kRaw]) {
+    const char *at = in_ring + ((uint32_t)pos & (kRingMask & ~3u));
+#pragma unroll
+    for (int k = 0; k < kRaw; k++) raw[k] = *reinterpret_cast<const uint32_t *>(at + 4 * k);
+  };
+  auto unpack = [&](const uint32_t (&raw)[kRaw], uint32_t ph, uint32_t *w) {
+    if (CHF == 1) {
+      const uint32_t sel = 0x00010203u + 0x01010101u * ph; /* bytes ph .. ph + 3 of a dword pair, most significant first */
+      w[0] = perm(raw[1], raw[0], sel);
+      if (BITS == 4) w[1] = perm(raw[2], raw[1], sel);
+    } else {
+      uint32_t e[kRaw - 1];
+#pragma unroll
+      for (int k = 0; k < kRaw - 1; k++) e[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], ph);
+      const uint32_t pick = 0x00020406u + c * 0x01010101u;
+      w[0] = perm(e[1], e[0], pick);
+      if (BITS == 4) w[1] = perm(e[3], e[2], pick);
+    }
+  };
+  auto put_pcm = [&](uint32_t x, const ChunkPcm &o) { /* x: the chunk's first PCM byte, relative to the block's */
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      *reinterpret_cast<u32x4 *>(out_ring + ((theta + x + (CHF == 1 ? 16u * h : 32u * h + 16u * c)) & kRingMask)) = o.v[h];
+  };
+
+  const int32_t s_pos = (int32_t)(code0 - in_base); /* first code byte behind the lead chunk, 0 <= s_pos < kG */
+  uint32_t raw[kRaw];
+  ChunkPcm pending; /* the packed PCM of the chunk just decoded: written to the ring after the next chunk's code bytes are asked for */
+  pending.v[0] = pending.v[1] = u32x4{0, 0, 0, 0};
+  if (lead) {
+    uint32_t w[2] = {0, 0};
+    fetch_raw(s_pos - T::kLeadBytes, raw);
+    unpack(raw, (uint32_t)(s_pos - T::kLeadBytes) & 3u, w);
+    int32_t y[kChunk];
+    y[0] = y0;
+    y[1] = y1;
+    y[2] = y2;
+    y[3] = y3;
+    decode_chunk16<BITS, T::kLead, true>(L, w, lds, y + kTaps, finish);
+    pending = pack_chunk_pcm<CHF, false>(y, c);
+  } else {
+    if (n > 0) dst[0] = (int16_t)y0;
+    if (n > 1) dst[ch] = (int16_t)y1;
+    if (n > 2) dst[2 * ch] = (int16_t)y2;
+    if (n > 3) dst[3 * ch] = (int16_t)y3;
+  }
+  wave_lds_fence();
+  put_granule(1, gn); /* over granule -1: header and lead chunk have been read */
+  load_granule(2, gn);
+  wave_lds_fence();
+  fetch_raw(s_pos, raw);
+  if (lead) put_pcm(0, pending);
+  wave_lds_fence();
+
+  /* ---- steady state, one iteration per chunk j of every row:
+   *   the last chunk of an input period: granule period + 2 replaces granule period (every row has read its
+   *     bytes of chunk j already - they are in `raw`);
+   *   odd j: output granule (j - 1) / 2 is complete in every row since chunk j - 1 and chunk j is about to write
+   *     over it in some: its pieces are read now and stored behind the chunk's arithmetic;
+   *   decode chunk j; ask for chunk j + 1's code bytes; write chunk j's PCM (that hides the read). */
+  const uint32_t ph = (uint32_t)s_pos & 3u;
+  int32_t pos = s_pos;
+  uint32_t x = T::kPcmBytes;
+  int32_t period = 0;
+  for (uint32_t j = 0; j < full_max; j++) {
+    if ((j + 1) % T::kInPeriod == 0) {
+      put_granule(period + 2, gn);
+      period++;
+      load_granule(period + 2, gn);
+    }
+    u32x4 leaving[T::kInst];
+    const bool store_now = (j & 1u) != 0;
+    if (store_now) read_granule((j - 1) >> 1, leaving);
+    if (j < full) {
+      uint32_t w[2] = {0, 0};
+      unpack(raw, ph, w);
+      int32_t y[kChunk];
+      decode_chunk16<BITS, kChunk, true>(L, w, lds, y, finish);
+      pending = pack_chunk_pcm<CHF, false>(y, c);
+    }
+    if (store_now) write_granule((j - 1) >> 1, leaving);
+    wave_lds_fence();
+    pos += T::kCb;
+    fetch_raw(pos, raw);
+    if (j < full) put_pcm(x, pending);
+    x += T::kPcmBytes;
+    wave_lds_fence();
+  }
+  /* what the rows still hold: the granules the loop has not stored */
+  for (uint32_t t = full_max >> 1; t <= (full_max >> 1) + 1; t++) {
+    u32x4 leaving[T::kInst];
+    read_granule(t, leaving);
+    write_granule(t, leaving);
+  }
+
+  /* ---- remaining units of the block, per lane: byte loads, bytes past the stream read as zero (decode_blocks_kernel) */
+  {
+    const uint32_t done = lead ? T::kLead + full * kChunk : 0u;
+    const uint32_t unit_stride = UB * ch;
+    const uint32_t base = body + c * UB;
+    for (uint32_t i = done; i < coded; i += US) {
+      const uint32_t o = base + (i / US) * unit_stride;
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < UB; k++) acc = (acc << 8) | (o + k < avail ? (uint32_t)src[o + k] : 0u);
+      acc <<= 32 - 8 * UB;
+#pragma unroll
+      for (int k = 0; k < US; k++) {
+        const int32_t y = finish(decode_step<BITS>(L, acc >> (32 - BITS), lds));
+        acc <<= BITS;
+        if (i + k < coded) dst[(uint64_t)(kTaps + i + k) * ch] = (int16_t)y;
+      }
+    }
+  }
+}
+
+} /* namespace aad */
+
+#endif /* AAD_DECODE_TILED_HIP_H */

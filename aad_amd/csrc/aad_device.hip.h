@@ -129,7 +129,13 @@ constexpr int kLdsBytesQuadEnc = kLdsWideOff + AAD_STEP_TABLE_LEN * 16 * kWideCo
  * dequantiser (dense_dequantise). */
 constexpr int kLdsDenseStepOff = (kLdsBytes + 15) & ~15;
 constexpr int kLdsDenseCodeOff = kLdsDenseStepOff + AAD_STEP_TABLE_LEN * 16;
-constexpr int kLdsBytesDenseDec = kLdsDenseCodeOff + 16 * 16;
+/* the same records in 8 bytes {bias << 29 | delta & 0xFFFF, sm21 << 27} (the addend's upper word is zero and costs the
+ * reader one v_mov_b32): sixteen of them are one row of the 64 banks a ds_read_b64 sees - no two codes share a bank,
+ * where the 16-byte records put codes c and c + 8 on the same banks and every ds_read_b96 takes eight LDS cycles.
+ * For the kernels whose waves share a busy LDS (the sector-tiled dense decoder) - a lone wave prefers the one wide
+ * lookup without the v_mov. */
+constexpr int kLdsDenseCode8Off = kLdsDenseCodeOff + 16 * 16;
+constexpr int kLdsBytesDenseDec = kLdsDenseCode8Off + 16 * 8;
 constexpr int kWideStepShift = 9; /* the encoders' wide records hold step << 9: a 24-bit factor for v_mul_hi_u32_u24 */
 __device__ __forceinline__ uint32_t wide4_addr(int32_t j, uint32_t copy_off) { return ((uint32_t)j & (0xFF0u * kIdxScale)) | copy_off; }
 /* byte offset of this lane's copy inside a slot of the encoders' wide table */
@@ -299,6 +305,7 @@ __device__ __forceinline__ void stage_dense_decode_tables(char *lds)
     e.z = (uint32_t)sm21 << (30 - kShift);
     e.w = 0;
     *reinterpret_cast<u32x4 *>(lds + kLdsDenseCodeOff + (code << 4)) = e;
+    *reinterpret_cast<u32x2 *>(lds + kLdsDenseCode8Off + (code << 3)) = u32x2{e.x, e.z};
   }
   __syncthreads();
 }

@@ -21,6 +21,7 @@
 #include "../../include/aad_hip.h"
 #include "aad_compare.hip.h"
 #include "aad_decode_split_launch.h"
+#include "aad_decode_tiled_launch.h"
 #include "aad_decode.hip.h"
 #include "aad_encode.hip.h"
 #include "aad_format.h"
@@ -227,7 +228,7 @@ MappingLimits mapping_limits(uint32_t bits, uint32_t channels)
 bool pick_quad(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels, uint32_t bits)
 {
   if (channels > 2) return false;
-  if (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_DENSE) return false;
+  if (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_DENSE || ctx->lane_mapping == AAD_HIP_LANE_MAPPING_DENSE_TILED) return false;
   if (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_QUAD || ctx->lane_mapping == AAD_HIP_LANE_MAPPING_QUAD_FUSED) return true;
   return recurrences <= mapping_limits(bits, channels).encode_quad;
 }
@@ -316,12 +317,15 @@ constexpr uint64_t kMaxResidualBytes = 1ull << 30;
 
 /* Decode mapping by batch size: see mapping_limits.  The context option forces one. */
 enum class DecodeMapping { Dense, QuadFused, QuadSplit };
+/* dense batches at and beyond this many recurrences take the sector-tiled kernel where it applies (aad_decode_tiled.hip.h) */
+constexpr uint64_t kTiledDecodeMin = 65536;
 
 DecodeMapping pick_decode_mapping(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels, uint32_t bits)
 {
   if (channels > 2) return DecodeMapping::Dense;
   switch (ctx->lane_mapping) {
-    case AAD_HIP_LANE_MAPPING_DENSE: return DecodeMapping::Dense;
+    case AAD_HIP_LANE_MAPPING_DENSE:
+    case AAD_HIP_LANE_MAPPING_DENSE_TILED: return DecodeMapping::Dense;
     case AAD_HIP_LANE_MAPPING_QUAD_FUSED: return DecodeMapping::QuadFused;
     case AAD_HIP_LANE_MAPPING_QUAD: return DecodeMapping::QuadSplit;
     default: break;
@@ -354,6 +358,10 @@ void launch_decode(const AADHipContext *ctx, const aad::DecodeArgs &a, int32_t *
   /* a split decode that could not have its scratch buffer: the fused kernel when the quad mapping is
    * forced, the dense one otherwise */
   const DecodeMapping pick = pick_decode_mapping(ctx, lanes, a.channels, BITS);
+  /* dense: the sector-tiled kernel for chip-filling batches (or when the option asks for it), where it applies */
+  if (pick == DecodeMapping::Dense && ctx->lane_mapping != AAD_HIP_LANE_MAPPING_DENSE &&
+      (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_DENSE_TILED || lanes >= kTiledDecodeMin) && aad::launch_decode_tiled(a, stream))
+    return;
   const bool quad = pick == DecodeMapping::QuadFused || (pick == DecodeMapping::QuadSplit && ctx->lane_mapping == AAD_HIP_LANE_MAPPING_QUAD);
   const uint64_t threads = quad ? lanes * 4 : lanes;
   const unsigned wg = pick_workgroup(threads);
@@ -449,6 +457,13 @@ AADApiResult decode_plan_init(const struct AADHeaderInfo *format, int32_t has_fi
   }
   args->mid_side = h.ch_process_method == AAD_CH_PROCESS_METHOD_MS;
   args->bits = h.bits_per_sample;
+  /* the sector-tiled dense decoder moves PCM in 16-byte pieces: every stream's PCM must start on a piece boundary */
+  args->pcm_aligned16 = 1;
+  for (uint32_t i = 0; i < num_streams; i++)
+    if ((streams[i].pcm_offset * 2u) % 16u != 0) {
+      args->pcm_aligned16 = 0;
+      break;
+    }
   /* Dense stereo 4-/2-bit decode opens every block with a 16-frame chunk, so its stores are whole
    * 64-byte granules exactly when every block's first frame is 64-byte aligned: a uniform layout
    * whose stream pitch and block length (in PCM bytes) are multiples of 64.  Only then are they
@@ -652,9 +667,9 @@ const char *AADHip_ContextLastError(const struct AADHipContext *ctx) { return ct
 
 void AADHipInternal_ContextOptionsFromEnvironment(struct AADHipContext *ctx)
 {
-  static const char *const kMappings[] = {"auto", "dense", "quad", "quad-fused"};
+  static const char *const kMappings[] = {"auto", "dense", "quad", "quad-fused", "dense-tiled"};
   static const char *const kTrialLanes[] = {"dual", "single"};
-  ctx->lane_mapping = option_from_env("AAD_HIP_MAPPING", kMappings, 4);
+  ctx->lane_mapping = option_from_env("AAD_HIP_MAPPING", kMappings, 5);
   ctx->trial_lanes = option_from_env("AAD_HIP_TRIAL_LANES", kTrialLanes, 2);
   const char *threads = getenv("AAD_HIP_STAGING_THREADS");
   if (threads != nullptr && threads[0] >= '1' && threads[0] <= '8' && threads[1] == '\0') ctx->staging_threads = threads[0] - '0';
@@ -672,7 +687,7 @@ AADApiResult AADHip_ContextSetOption(struct AADHipContext *ctx, int32_t option, 
   if (ctx == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
   switch (option) {
     case AAD_HIP_OPTION_LANE_MAPPING:
-      if (value < AAD_HIP_LANE_MAPPING_AUTO || value > AAD_HIP_LANE_MAPPING_QUAD_FUSED) return AAD_APIRESULT_INVALID_ARGUMENT;
+      if (value < AAD_HIP_LANE_MAPPING_AUTO || value > AAD_HIP_LANE_MAPPING_DENSE_TILED) return AAD_APIRESULT_INVALID_ARGUMENT;
       ctx->lane_mapping = value;
       return AAD_APIRESULT_OK;
     case AAD_HIP_OPTION_TRIAL_LANES:

@@ -563,6 +563,13 @@ def main():
                     help="N = 1: skip the batched-file leg under a one-rank RCCL group (BASELINE config 5's code path with the collectives forced)")
     args = ap.parse_args()
 
+    # Rank 0 owes the driver ONE line on stdout.  RCCL prints a version banner on stdout when its first communicator
+    # comes up (seen on the GPU box: five lines in front of the JSON), so file descriptor 1 is pointed at stderr for
+    # the whole run - native libraries included - and the line goes out through a saved duplicate at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
@@ -790,7 +797,8 @@ def main():
                 line["end_to_end"]["host_memory_api"]["decode_msps"] / cpu[args.trials]["decode_msps"], 1)
     engine.close()
     if rank == 0:
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

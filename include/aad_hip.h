@@ -69,7 +69,7 @@ AADApiResult AADHip_ContextSynchronize(struct AADHipContext *context);
 const char *AADHip_ContextLastError(const struct AADHipContext *context);
 
 /* Launch options of a context.  Defaults: the environment variables AAD_HIP_MAPPING
- * (auto | dense | quad | quad-fused), AAD_HIP_TRIAL_LANES (dual | single),
+ * (auto | dense | quad | quad-fused | dense-tiled), AAD_HIP_TRIAL_LANES (dual | single),
  * AAD_HIP_STAGING_THREADS (1..8) and AAD_HIP_TILE_KBYTES, read ONCE when the context is created; the library never calls getenv afterwards.  An option holds for every later
  * ...Run / ...Batch call of the context; set it from the thread that owns the context. */
 enum AADHipOption {
@@ -90,7 +90,8 @@ enum AADHipLaneMapping {
   AAD_HIP_LANE_MAPPING_AUTO = 0,      /* by batch size (the default) */
   AAD_HIP_LANE_MAPPING_DENSE = 1,     /* one lane per recurrence */
   AAD_HIP_LANE_MAPPING_QUAD = 2,      /* four lanes per recurrence; decode: step-index scan on other waves */
-  AAD_HIP_LANE_MAPPING_QUAD_FUSED = 3 /* four lanes per recurrence; decode: one fused kernel */
+  AAD_HIP_LANE_MAPPING_QUAD_FUSED = 3, /* four lanes per recurrence; decode: one fused kernel */
+  AAD_HIP_LANE_MAPPING_DENSE_TILED = 4 /* one lane per recurrence, memory moved in whole sectors / lines through LDS where the layout allows (else: dense) */
 };
 enum AADHipTrialLanes {
   AAD_HIP_TRIAL_LANES_DUAL = 0,  /* trial search on the quad mapping: a second group of lanes runs the probe and encodes every candidate beside the chain */

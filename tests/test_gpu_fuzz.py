@@ -26,7 +26,7 @@ def engine():
 SEEDS = int(os.environ.get("AAD_FUZZ_SEEDS", "8"))  # a one-off deeper run: AAD_FUZZ_SEEDS=200 pytest -m gpu tests/test_gpu_fuzz.py
 
 
-@pytest.mark.parametrize("mapping", ["dense", "quad", "quad-fused", "auto"])
+@pytest.mark.parametrize("mapping", ["dense", "dense-tiled", "quad", "quad-fused", "auto"])
 @pytest.mark.parametrize("seed", range(SEEDS))
 def test_random_parameter_sets(engine, mapping, seed):
     rng = np.random.default_rng(1000 + seed)
@@ -65,7 +65,7 @@ def test_random_parameter_sets(engine, mapping, seed):
         engine.set_tile_kbytes(0)
 
 
-@pytest.mark.parametrize("mapping", ["dense", "quad", "quad-fused"])
+@pytest.mark.parametrize("mapping", ["dense", "dense-tiled", "quad", "quad-fused"])
 @pytest.mark.parametrize("seed", range(max(4, SEEDS // 2)))
 def test_random_device_resident_plans(engine, mapping, seed):
     """Device-resident plans with hand-made stream tables: uniform layouts at odd alignments (the

@@ -32,7 +32,7 @@ def engine():
     e.close()
 
 
-@pytest.fixture(params=["dense", "quad", "quad-fused"])
+@pytest.fixture(params=["dense", "dense-tiled", "quad", "quad-fused"])
 def mapping(request, engine):
     """The lane mappings of the kernels (one lane per recurrence / four lanes per recurrence; for the
     quad decoder both the two-kernel form and the single fused kernel): the host picks by batch
