@@ -80,7 +80,7 @@ struct File {
 };
 
 struct Options {
-  int mode; /* 'e' 'd' 'r' 'g' 'c' */
+  int mode; /* 'e' 'd' 'r' 'g' 'c'; 'i' never reaches the device slots */
   uint64_t wave_bytes;
   const char *outdir;
   struct AADEncodeParameter param;
@@ -528,12 +528,102 @@ static void *writer_main(void *arg)
 
 /* ---- main ---------------------------------------------------------------------------------- */
 
+static void print_usage_lines(FILE *to)
+{
+  fprintf(to, "usage: aad_batch -e|-r|-g [-b bits] [-s max_block_size] [-t trials] [-m] [-D dev,dev,...] -o OUTDIR [-l LIST] in.wav...\n"
+              "       aad_batch -c       [-b bits] [-s max_block_size] [-t trials] [-m] [-D dev,dev,...] [-l LIST] in.wav...\n"
+              "       aad_batch -d [-D dev,dev,...] -o OUTDIR [-l LIST] in.aad...\n"
+              "       aad_batch -i [-l LIST] in.aad...\n"
+              "       aad_batch -h | -v\n");
+}
+
 static int usage(void)
 {
-  fprintf(stderr, "usage: aad_batch -e|-r|-g [-b bits] [-s max_block_size] [-t trials] [-m] [-D dev,dev,...] -o OUTDIR [-l LIST] in.wav...\n"
-                  "       aad_batch -c       [-b bits] [-s max_block_size] [-t trials] [-m] [-D dev,dev,...] [-l LIST] in.wav...\n"
-                  "       aad_batch -d [-D dev,dev,...] -o OUTDIR [-l LIST] in.aad...\n");
+  print_usage_lines(stderr);
   return 2;
+}
+
+/* -h: the reference's option table (src/main.c:20-58) in the layout its parser prints it
+ * (src/command_line_parser.c:81-100: "  -c, --long" in 20 columns, "(needs argument)" in 18, the text),
+ * then the options only this front end has */
+static int print_help(void)
+{
+  static const struct { char c; const char *name; int arg; const char *text; } spec[] = {
+    {'e', "encode", 0, "Encode mode (wav file -> .aad file)"},
+    {'d', "decode", 0, "Decode mode (.aad file -> wav file)"},
+    {'r', "reconstruct", 0, "Reconstruction mode (wav file -> (encode -> decode) -> decoded wav file)"},
+    {'g', "gap", 0, "Gap(residual output) mode (wav file -> (encode -> decode) -> residual wav file)"},
+    {'c', "calculate", 0, "Calculate statistics(e.g. RMS error) between original and reconstructed wav"},
+    {'i', "information", 0, "Show information of encoded .aad file"},
+    {'b', "bits-per-sample", 1, "Specify bits per sample(in 2,3,4) (default: 4)"},
+    {'s', "max-block-size", 1, "Specify max block size (default: 1024)"},
+    {'t', "num-encode-trials", 1, "Specify number of encode Trials (default: 2)"},
+    {'m', "ms-conversion", 0, "Switch to use LR to MS conversion (default: no)"},
+    {'h', "help", 0, "Show help message"},
+    {'v', "version", 0, "Show version information"},
+    {'o', "output-dir", 1, "Directory the outputs go to, as <input stem>.aad / .wav (every mode but -c and -i)"},
+    {'l', "list", 1, "File with one input path per line, in addition to the paths on the command line"},
+    {'D', "devices", 1, "Comma-separated device indices; a device may be named more than once (default: AAD_HIP_DEVICE or 0)"},
+  };
+  size_t k;
+  print_usage_lines(stdout);
+  printf("options: \n");
+  for (k = 0; k < sizeof(spec) / sizeof(spec[0]); k++) {
+    char command[64];
+    snprintf(command, sizeof(command), "  -%c, --%s", spec[k].c, spec[k].name);
+    printf("%-20s %-18s  %s \n", command, spec[k].arg ? "(needs argument)" : "", spec[k].text);
+  }
+  return 0;
+}
+
+/* -v: the reference's line (src/main.c:511-514) */
+static int print_version(void)
+{
+  printf("AAD(Ayashi Adaptive Differential pulse code modulation) encoder/decoder Version.%d \n", AAD_CODEC_VERSION);
+  return 0;
+}
+
+/* -i: the header of every input, in the reference's ten lines (src/main.c:229-272).  No device work.  With more than
+ * one input every report is preceded by a line naming the file. */
+static int print_information(char *const *paths, int npaths)
+{
+  static const char *const ch_process[] = {"None", "MS-Conversion"};
+  int i, rc = 0;
+  for (i = 0; i < npaths; i++) {
+    uint8_t buffer[AAD_HEADER_SIZE];
+    struct AADHeaderInfo h;
+    AADApiResult ret;
+    FILE *fp = fopen(paths[i], "rb");
+    if (fp == NULL) {
+      fprintf(stderr, "Failed to open %s. \n", paths[i]);
+      rc = 1;
+      continue;
+    }
+    if (fread(buffer, 1, AAD_HEADER_SIZE, fp) < AAD_HEADER_SIZE) {
+      fprintf(stderr, "Failed to read from %s. \n", paths[i]);
+      fclose(fp);
+      rc = 1;
+      continue;
+    }
+    fclose(fp);
+    if ((ret = AADDecoder_DecodeHeader(buffer, AAD_HEADER_SIZE, &h)) != AAD_APIRESULT_OK) {
+      fprintf(stderr, "Failed to read header. API result: %d \n", (int)ret);
+      rc = 1;
+      continue;
+    }
+    if (npaths > 1) printf("%s\n", paths[i]);
+    printf("%-30s %-9d   \n", "Format Version:", (int)h.format_version);
+    printf("%-30s %-9d   \n", "Codec Version:", (int)h.codec_version);
+    printf("%-30s %-9d   \n", "Number of Channels:", (int)h.num_channels);
+    printf("%-30s %-9d   \n", "Number of Samples per Channel:", (int)h.num_samples);
+    printf("%-30s %-9d   \n", "Sampling Rate:", (int)h.sampling_rate);
+    printf("%-30s %-9d   \n", "Bits per Sample:", (int)h.bits_per_sample);
+    printf("%-30s %-9d   \n", "Block size:", (int)h.block_size);
+    printf("%-30s %-9d   \n", "Number of Samples per Block:", (int)h.num_samples_per_block);
+    printf("%-30s %-9s   \n", "Channel Processing:", ch_process[h.ch_process_method == AAD_CH_PROCESS_METHOD_MS ? 1 : 0]);
+    printf("%-30s %-8.1f \n", "Bits per Second(bps):", (8.0f * (double)h.block_size * h.sampling_rate) / h.num_samples_per_block);
+  }
+  return rc;
 }
 
 static int is_opt(const char *arg, const char *shortname, const char *longname)
@@ -603,6 +693,14 @@ int main(int argc, char **argv)
     else if (is_opt(a, "-r", "--reconstruct")) opt.mode = 'r';
     else if (is_opt(a, "-g", "--gap")) opt.mode = 'g';
     else if (is_opt(a, "-c", "--calculate")) opt.mode = 'c';
+    else if (is_opt(a, "-i", "--information")) opt.mode = 'i';
+    else if (is_opt(a, "-h", "--help")) { /* as in the reference: help and version win over everything else */
+      free(paths);
+      return print_help();
+    } else if (is_opt(a, "-v", "--version")) {
+      free(paths);
+      return print_version();
+    }
     else if (is_opt(a, "-m", "--ms-conversion")) opt.param.ch_process_method = AAD_CH_PROCESS_METHOD_MS;
     else if (has_value && is_opt(a, "-b", "--bits-per-sample")) opt.param.bits_per_sample = (uint16_t)strtol(argv[++i], NULL, 10);
     else if (has_value && is_opt(a, "-s", "--max-block-size")) opt.param.max_block_size = (uint16_t)strtol(argv[++i], NULL, 10);
@@ -613,7 +711,7 @@ int main(int argc, char **argv)
     else if (a[0] == '-' && a[1] != 0) goto bad_usage;
     else paths[npaths++] = argv[i];
   }
-  if (opt.mode == 0 || (opt.mode != 'c' && opt.outdir == NULL)) goto bad_usage;
+  if (opt.mode == 0 || (opt.mode != 'c' && opt.mode != 'i' && opt.outdir == NULL)) goto bad_usage;
 
   if (list != NULL) { /* one path per line; LF, CRLF or bare CR endings */
     struct File lf;
@@ -639,6 +737,10 @@ int main(int argc, char **argv)
     }
   }
   if (npaths == 0) goto bad_usage;
+  if (opt.mode == 'i') {
+    rc = print_information(paths, npaths);
+    goto cleanup;
+  }
 
   for (ndev = 0; devarg != NULL && *devarg && ndev < MAX_DEVICES;) {
     char *end;

@@ -41,12 +41,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-# VALU issue peak (same guide, "Wave scheduling" + cycle constants; confirmed for the integer, DPP, SDWA and 64-bit
-# multiply-add instructions these kernels use by tools/microbench/ubench_rate.hip, profiles/r03_microbench_valu_rate.txt):
-# a SIMD retires one wave64 vector instruction per 2 cycles once two or more waves share it; ONE wave alone gets an
-# issue slot every ~4 cycles.  256 CUs x 4 SIMDs at 2.4 GHz.
-SIMDS, CLOCK_GHZ, CYCLES_PER_VALU_INST, LONE_WAVE_CYCLES_PER_INST = 1024, 2.4, 2.0, 4.0
-VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / CYCLES_PER_VALU_INST  # G wave-instructions / s
+# VALU issue peak.  tools/microbench/ubench_rate.hip (profiles/r03_microbench_valu_rate.txt) measured what a SIMD retires per
+# wave64 vector instruction with 1, 2, 4 and 8 waves on it: 2 cycles (the guide's figure) for v_add/sub_u32, v_and/or/xor_b32,
+# v_lshrrev/ashrrev, v_mov_b32, v_add/mul_f32 once two waves share the SIMD - and 4 cycles, whatever the wave count, for
+# everything these kernels' recurrences are made of: integer multiplies (24- and 32-bit), v_mad_i64_i32 / v_mad_u64_u32, every
+# three-operand VOP3 form (v_and_or, v_lshl_or, v_add3, v_med3, v_perm, v_bfe, v_mad_i32_i24), v_min/max, v_lshlrev, conversions,
+# DPP and SDWA forms, v_cmp, f64 and packed adds (v_fma_f32: 3.7).  The encoder's own mix ran at 3.80, the decoder's at 4.00 cycles
+# per instruction at 8 waves per SIMD; ONE wave alone is offered a slot every 4.1-4.6 cycles.  256 CUs x 4 SIMDs, 2.4 GHz nominal
+# (a chip-filling launch of these kernels holds ~1.85 GHz, GRBM_GUI_ACTIVE / duration: fractions against the nominal clock
+# are the conservative ones).
+SIMDS, CLOCK_GHZ, FULL_RATE_CYCLES, LONE_WAVE_CYCLES_PER_INST = 1024, 2.4, 2.0, 4.0
+MIX_CYCLES = {"encode": 3.80, "decode": 4.00}  # cycles per instruction of the kernels' instruction mix (ubench_rate: encoder_mix, decoder_mix)
 STAMP_FILE = os.path.join(ROOT, "profiles", "r03_pmc_stamp.json")
 
 
@@ -96,23 +101,33 @@ def traffic_fields(stamp, note, algorithmic):
                                      "128-B request); traffic_raw = FETCH_SIZE + WRITE_SIZE as counted"}
 
 
-def valu_fields(stamp, note, kernel_ms, samples_per_recurrence):
-    """The bound that actually applies (SURVEY.md section 8d "state both"): wave-instructions per second against
-    what the chip's 1024 SIMDs can issue.  Instruction counts from the stamped PMC pass (SQ_INSTS_VALU,
-    SQ_WAVES), the duration is THIS run's (HIP events)."""
+def valu_fields(stamp, note, kernel_ms, samples_per_recurrence, role):
+    """The bound that actually applies (SURVEY.md section 8d "state both"): wave-instructions per second against what the
+    chip's 1024 SIMDs can issue of THIS instruction mix (MIX_CYCLES), and against the full-rate figure.  Instruction counts
+    from the stamped PMC pass (SQ_INSTS_VALU, SQ_WAVES), the duration is THIS run's (HIP events)."""
     if not stamp or "SQ_INSTS_VALU" not in stamp or not stamp.get("SQ_WAVES"):
         return {"frac": None, "source": note}
     insts, waves = stamp["SQ_INSTS_VALU"], stamp["SQ_WAVES"]
     rate = insts / (kernel_ms * 1e-3) / 1e9  # G wave-instructions / s
+    mix = MIX_CYCLES[role]
+    peak_mix, peak_full = SIMDS * CLOCK_GHZ / mix, SIMDS * CLOCK_GHZ / FULL_RATE_CYCLES
     occupied = min(waves, SIMDS)
     v = {"insts_per_launch": int(insts), "waves": int(waves),
          # wave-instructions a recurrence's wave issues per sample of the chain it walks (whole kernel: headers, tails,
          # loads and stores included)
          "insts_per_sample": round(insts / waves / samples_per_recurrence, 2),
          "insts_per_wave": round(insts / waves, 1),
-         "wave_insts_per_s": round(rate * 1e9, 1), "peak_wave_insts_per_s": VALU_PEAK_GINST * 1e9,
-         "cycles_per_inst_assumed": CYCLES_PER_VALU_INST, "clock_ghz_assumed": CLOCK_GHZ,
-         "frac": round(rate / VALU_PEAK_GINST, 5), "source": note + " (SQ_INSTS_VALU, SQ_WAVES); duration from this run"}
+         "wave_insts_per_s": round(rate * 1e9, 1), "peak_wave_insts_per_s": round(peak_mix * 1e9, 1),
+         "cycles_per_inst_assumed": mix, "clock_ghz_assumed": CLOCK_GHZ,
+         "frac": round(rate / peak_mix, 5),
+         "peak_full_rate_wave_insts_per_s": peak_full * 1e9, "frac_of_full_rate": round(rate / peak_full, 5),
+         "peak_note": "peak = 1024 SIMDs x 2.4 GHz / %.2f cycles: what a SIMD retires of this kernel's instruction mix (multiplies, "
+                      "64-bit multiply-adds, VOP3, DPP, SDWA, conversions: 4 cycles each on gfx950; only add/sub/logic/right-shift/mov "
+                      "go at the full rate of 2) - profiles/r03_microbench_valu_rate.txt" % mix,
+         "source": note + " (SQ_INSTS_VALU, SQ_WAVES); duration from this run"}
+    if "SQ_ACTIVE_INST_VALU" in stamp and stamp.get("GRBM_GUI_ACTIVE"):
+        # clock-independent: quad-cycles in which a SIMD issued VALU work / SIMD-cycles of the profiled launch
+        v["valu_active_frac_pmc"] = round(stamp["SQ_ACTIVE_INST_VALU"] * 4.0 / SIMDS / (stamp["GRBM_GUI_ACTIVE"] / 8.0), 4)
     if waves <= SIMDS:
         # fewer waves than SIMDs: each wave is alone on its SIMD and is offered an issue slot every ~4 cycles
         lone_peak = occupied * CLOCK_GHZ / LONE_WAVE_CYCLES_PER_INST
@@ -120,8 +135,7 @@ def valu_fields(stamp, note, kernel_ms, samples_per_recurrence):
         v["lone_wave_issue_frac"] = round(rate / lone_peak, 4)
         v["lone_wave_note"] = ("%d waves on %d SIMDs: a wave alone on its SIMD issues at most one instruction per ~%.0f cycles, so "
                                "this launch can use at most %.3f of the chip's VALU peak; lone_wave_issue_frac is the share of "
-                               "THOSE slots it fills" % (waves, SIMDS, LONE_WAVE_CYCLES_PER_INST,
-                                                         lone_peak / VALU_PEAK_GINST))
+                               "THOSE slots it fills" % (waves, SIMDS, LONE_WAVE_CYCLES_PER_INST, lone_peak / peak_mix))
     return v
 
 
@@ -667,10 +681,10 @@ def main():
                                  "of the previous step occupies the other half of the chip meanwhile (`serial.encode_kernel_ms` is the "
                                  "same kernel with the chip to itself)" % args.event_every if not args.serial else
                                  "HIP events on the launch stream, on every %d-th step of the timed regions" % args.event_every,
-               "valu": valu_fields(stamp_e, note_e, m["enc_ms"], samples),
+               "valu": valu_fields(stamp_e, note_e, m["enc_ms"], samples, "encode"),
                "decode_kernel": dict({"kernel": (stamp_d or {}).get("kernel", "aad::decode_split_kernel<4> (quad batches) / aad::decode_blocks_kernel<4> (dense)"),
                                       "achieved": round(dec_gbs, 3), "frac": round(dec_gbs / HBM_PEAK_GBS, 6), "kernel_ms": round(m["dec_ms"], 5),
-                                      "valu": valu_fields(stamp_d, note_d, m["dec_ms"], hd.num_samples_per_block)},
+                                      "valu": valu_fields(stamp_d, note_d, m["dec_ms"], hd.num_samples_per_block, "decode")},
                                      **traffic_fields(stamp_d, note_d, algorithmic)),
                "note": "a 2000-recurrence batch is bound by per-wave instruction issue, not by bandwidth (DESIGN.md \"Kernels\"): `valu` "
                        "carries that bound; `saturated` shows the same kernels on a chip-filling batch"}),
@@ -729,7 +743,7 @@ def main():
             st, note = pmc_stamp("saturated", role, big_streams, samples)
             line["saturated"][role] = dict({"kernel": (st or {}).get("kernel"), "kernel_ms": round(kms, 5)},
                                            **traffic_fields(st, note, int(round(nb * bps))),
-                                           **{"valu": valu_fields(st, note, kms, per_rec)})
+                                           **{"valu": valu_fields(st, note, kms, per_rec, role)})
 
         if extras:
             # the other fast-path geometries on chip-filling batches of one-block streams (524 288 recurrences each),

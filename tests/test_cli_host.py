@@ -14,6 +14,48 @@ def _run(args, **kw):
     return subprocess.run([CLI] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60, **kw)
 
 
+def test_information_help_and_version_match_the_reference_cli(tmp_path):
+    """-i / -h / -v (reference src/main.c:229-272, 505-547): the text the compiled reference CLI printed
+    (tests/golden/cli_info.json, make_cli_info_golden.py), for images rebuilt here with the oracle.  No device work."""
+    import hashlib
+    import json
+    import oracle_binding as ob
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cli_info.json")))
+    paths = []
+    for k, c in enumerate(gold["cases"]):
+        img = ob.encode(synth_pcm(1, c["samples"], c["channels"], seed=c["seed"])[0], c["bits"], c["max_block_size"], c["rate"], c["ms"], 0)
+        assert hashlib.sha256(img).hexdigest() == c["image_sha256"]  # the bytes the reference CLI wrote
+        p = tmp_path / ("case%d.aad" % k)
+        p.write_bytes(img)
+        paths.append(str(p))
+        r = _run(["-i", str(p)])
+        assert r.returncode == 0 and r.stdout == c["information"], (k, r.stdout, r.stderr)
+        assert _run(["--information", str(p)]).stdout == c["information"]
+    # several inputs: every report behind a line that names the file
+    r = _run(["-i"] + paths)
+    assert r.returncode == 0 and r.stdout == "".join(p + "\n" + c["information"] for p, c in zip(paths, gold["cases"]))
+    # errors as the reference words them (src/main.c:240-258), the other files are still reported
+    bad = tmp_path / "short.aad"
+    bad.write_bytes(b"AAD\0\0\0")
+    r = _run(["-i", str(bad), paths[0]])
+    assert r.returncode == 1 and "Failed to read from" in r.stderr and gold["cases"][0]["information"] in r.stdout
+    junk = tmp_path / "junk.aad"
+    junk.write_bytes(b"RIFF" + bytes(40))
+    r = _run(["-i", str(junk)])
+    assert r.returncode == 1 and "Failed to read header. API result:" in r.stderr
+    assert _run(["-i", str(tmp_path / "missing.aad")]).returncode == 1
+    # -v: the reference's line; -h: its option table line for line, this front end's own options behind it
+    for flag in ("-v", "--version"):
+        r = _run([flag])
+        assert r.returncode == 0 and r.stdout == gold["version"]
+    r = _run(["-h"])
+    assert r.returncode == 0 and "options: \n" in r.stdout
+    lines = [l for l in r.stdout.splitlines(True) if l.startswith("  -")]
+    assert lines[:len(gold["help_option_lines"])] == gold["help_option_lines"]
+    assert any("--devices" in l for l in lines) and any("--list" in l for l in lines) and any("--output-dir" in l for l in lines)
+    assert _run(["-e", "-h", "x.wav"]).returncode == 0  # help wins over a mode, as in the reference
+
+
 def test_usage_errors():
     assert _run([]).returncode == 2
     assert _run(["-e", "x.wav"]).returncode == 2          # no output directory
