@@ -55,7 +55,7 @@ STREAM_DESC_DTYPE = np.dtype([("pcm_offset", "<u8"), ("data_offset", "<u8"), ("d
                               ("num_samples", "<u4"), ("reserved", "<u4")])
 ERROR_STATS_DTYPE = np.dtype([("rms_error", "<f8"), ("mean_abs_error", "<f8"), ("max_abs_error", "<f8")])  # AADHipErrorStats
 RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL = 0, 1  # enum AADHipReconstructOutput
-OPTION_LANE_MAPPING, OPTION_TRIAL_LANES, OPTION_STAGING_THREADS, OPTION_TILE_KBYTES = 0, 1, 2, 3  # enum AADHipOption
+OPTION_LANE_MAPPING, OPTION_TRIAL_LANES, OPTION_STAGING_THREADS, OPTION_TILE_KBYTES, OPTION_COMPARE_ORDER = 0, 1, 2, 3, 4  # enum AADHipOption
 LANE_MAPPINGS = {"auto": 0, "dense": 1, "quad": 2, "quad-fused": 3, "dense-tiled": 4}  # enum AADHipLaneMapping
 TRIAL_LANES = {"dual": 0, "single": 1}  # enum AADHipTrialLanes
 LANE_STATE_DTYPE = np.dtype([("weight", "<i4", (4,)), ("history", "<i4", (4,)),

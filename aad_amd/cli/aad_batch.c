@@ -35,13 +35,16 @@
  * up to 8192 files or 64 GB (mapped files cost page cache, not process memory): an encoder launch
  * takes about `blocks of the longest file` x 64 us (x3 with the default trial search) however many
  * files it holds - the blocks of a file are chained - so the more long files share a wave the
- * better; the library cuts the wave into tiles that fit its pinned staging blocks by itself.
+ * better; for -e and -d the library cuts the wave into tiles that fit its pinned staging blocks by
+ * itself.  The reconstruction modes (-r / -g / -c) are staged whole by the library, so their waves
+ * stop at 256 MB of input.
  *
  * Output names are OUTDIR/<stem><ext>; two inputs with the same stem would overwrite each other,
  * so that is refused up front.  Every output is byte-identical to what the reference CLI writes
  * for the same input.  Host C only; all codec work happens in libaad_hip.so.
  */
 #define _POSIX_C_SOURCE 200809L
+#include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
 #include <signal.h>
@@ -56,6 +59,9 @@
 #include "../../include/aad_wav.h"
 
 #define MAX_DEVICES 16
+/* The reconstruction modes (-r / -g / -c) go through AADHip_ReconstructBatch, the one host-memory entry point the library
+ * does NOT cut into tiles: the whole call is staged in one pinned and one device block.  Their waves are kept small here. */
+#define RECONSTRUCT_WAVE_BYTES (256ull << 20)
 #define WAVE_BYTES_DEFAULT (64ull << 30) /* bytes a wave of one device slot spans, max(inputs, outputs) ($AAD_BATCH_WAVE_BYTES overrides: tests) */
 #define WAVE_FILES 8192
 #define QUEUE_DEPTH 2
@@ -242,12 +248,22 @@ static void map_output(const struct Options *opt, struct File *f, const char *ex
   /* `-r -o .` on ./x.wav: the output IS the (mapped) input.  Truncating it now would pull the pages from
    * under the device stage; the buffered path writes it after the input has been consumed, as before. */
   if (stat(path, &st) == 0 && (uint64_t)st.st_dev == f->in_dev && (uint64_t)st.st_ino == f->in_ino) return;
+  /* The file is built under "<name>.part" and gets its name when it is complete (finish_mapped): whatever ends this
+   * process early - SIGBUS on a page the device cannot back included - never leaves a file of the final name and size
+   * with holes that read back as silence.  Its blocks are reserved up front (posix_fallocate: a full device is reported
+   * HERE, and the caller falls back to the buffered write, which names the failing file); a file system that cannot
+   * reserve (EOPNOTSUPP / EINVAL) gets the sparse file of before. */
+  if (strlen(path) + 6 > sizeof(path)) return;
+  strcat(path, ".part");
   fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0666);
   if (fd < 0) return;
-  if (ftruncate(fd, (off_t)(head_size + body_size)) != 0) {
-    close(fd);
-    (void)unlink(path);
-    return;
+  {
+    const int e = posix_fallocate(fd, 0, (off_t)(head_size + body_size));
+    if ((e != 0 && e != EOPNOTSUPP && e != EINVAL) || (e != 0 && ftruncate(fd, (off_t)(head_size + body_size)) != 0)) {
+      close(fd);
+      (void)unlink(path);
+      return;
+    }
   }
   m = mmap(NULL, (size_t)(head_size + body_size), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   close(fd);
@@ -265,15 +281,22 @@ static void map_output(const struct Options *opt, struct File *f, const char *ex
 /* a mapped output is complete once the device stage is done with it; returns 0 on failure */
 static int finish_mapped(const struct Options *opt, struct File *f, const char *ext, int keep)
 {
-  char path[4096];
+  char path[4096], part[4096 + 8];
   const uint64_t final_size = f->out_head + f->out_size;
-  int ok = 1;
   (void)munmap(f->out_map, (size_t)f->out_map_size);
   f->out_map = f->out = NULL;
   if (!out_path(path, sizeof(path), opt->outdir, f->path, ext)) return 0;
-  if (!keep) return unlink(path) == 0;
-  if (final_size != f->out_map_size) ok = truncate(path, (off_t)final_size) == 0;
-  return ok;
+  snprintf(part, sizeof(part), "%s.part", path);
+  if (!keep) return unlink(part) == 0;
+  if (final_size != f->out_map_size && truncate(part, (off_t)final_size) != 0) {
+    (void)unlink(part);
+    return 0;
+  }
+  if (rename(part, path) != 0) { /* complete: now it gets its name */
+    (void)unlink(part);
+    return 0;
+  }
+  return 1;
 }
 
 static int write_out(const char *outdir, const char *inpath, const char *ext, const uint8_t *head, size_t head_size,
@@ -346,7 +369,9 @@ static void *reader_main(void *arg)
     /* a wave is sized by what it holds in memory at once: its inputs are mapped, its outputs are
      * allocated - a quarter of the input for -e, up to four times the input for -d */
     const uint64_t weight = s->opt->mode == 'd' ? 4 : 1;
-    while (i < s->nfiles && (i == w.first || (bytes + weight * s->files[i]->disk_size <= s->opt->wave_bytes && i - w.first < WAVE_FILES))) {
+    const int reconstruct = s->opt->mode == 'r' || s->opt->mode == 'g' || s->opt->mode == 'c';
+    const uint64_t wave_bytes = reconstruct && s->opt->wave_bytes > RECONSTRUCT_WAVE_BYTES ? RECONSTRUCT_WAVE_BYTES : s->opt->wave_bytes;
+    while (i < s->nfiles && (i == w.first || (bytes + weight * s->files[i]->disk_size <= wave_bytes && i - w.first < WAVE_FILES))) {
       bytes += weight * s->files[i]->disk_size;
       if (!load_file(s->opt, s->files[i])) w.failed = 1;
       i++;

@@ -84,6 +84,7 @@ struct AADHipContext {
   /* AADHip_ContextSetOption; the defaults come from the environment ONCE, at creation */
   int32_t lane_mapping; /* enum AADHipLaneMapping */
   int32_t trial_lanes;  /* enum AADHipTrialLanes */
+  int32_t compare_sequential; /* AAD_HIP_OPTION_COMPARE_ORDER: the -c sums always in the reference's order */
   int64_t tile_bytes;      /* 0 = the built-in tile budget of the host-memory path, else that many bytes */
   void *d_state;           /* predictor states of a group of streams between its tiles (host-memory encode) */
   size_t state_capacity;   /* in records */
@@ -671,6 +672,8 @@ void AADHipInternal_ContextOptionsFromEnvironment(struct AADHipContext *ctx)
   static const char *const kTrialLanes[] = {"dual", "single"};
   ctx->lane_mapping = option_from_env("AAD_HIP_MAPPING", kMappings, 5);
   ctx->trial_lanes = option_from_env("AAD_HIP_TRIAL_LANES", kTrialLanes, 2);
+  static const char *const kCompareOrders[] = {"auto", "sequential"};
+  ctx->compare_sequential = option_from_env("AAD_HIP_COMPARE_ORDER", kCompareOrders, 2);
   const char *threads = getenv("AAD_HIP_STAGING_THREADS");
   if (threads != nullptr && threads[0] >= '1' && threads[0] <= '8' && threads[1] == '\0') ctx->staging_threads = threads[0] - '0';
   const char *tile = getenv("AAD_HIP_TILE_KBYTES");
@@ -693,6 +696,10 @@ AADApiResult AADHip_ContextSetOption(struct AADHipContext *ctx, int32_t option, 
     case AAD_HIP_OPTION_TRIAL_LANES:
       if (value != AAD_HIP_TRIAL_LANES_DUAL && value != AAD_HIP_TRIAL_LANES_SINGLE) return AAD_APIRESULT_INVALID_ARGUMENT;
       ctx->trial_lanes = value;
+      return AAD_APIRESULT_OK;
+    case AAD_HIP_OPTION_COMPARE_ORDER:
+      if (value != 0 && value != 1) return AAD_APIRESULT_INVALID_ARGUMENT;
+      ctx->compare_sequential = value;
       return AAD_APIRESULT_OK;
     case AAD_HIP_OPTION_STAGING_THREADS:
       if (value < 0 || value > 8) return AAD_APIRESULT_INVALID_ARGUMENT;
@@ -899,7 +906,16 @@ void staged_span(AADHipContext *ctx, uint32_t first, uint32_t count, const std::
       body(first, count);
       return;
     }
-    for (unsigned t = 1; t < want; t++) ctx->pool->threads.emplace_back(staging_pool_main, ctx->pool, t);
+    /* These entry points are extern "C": an exception must not leave them.  A thread that cannot be created
+     * (RLIMIT_NPROC, a cgroup's pids limit: std::system_error) ends the pool - the threads that did start are joined - and
+     * the caller copies alone. */
+    try {
+      for (unsigned t = 1; t < want; t++) ctx->pool->threads.emplace_back(staging_pool_main, ctx->pool, t);
+    } catch (...) {
+      staging_pool_stop(ctx);
+      body(first, count);
+      return;
+    }
   }
   StagingPool *p = ctx->pool;
   const unsigned parts = (unsigned)p->threads.size() + 1;
@@ -1436,6 +1452,13 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
     if (!hop(ctx, ctx->computed[b], route.run, route.down)) break;
     {
       f.pieces = cut_pieces(f.cost, n, !piped, f.piece_end);
+      /* piece_done[] is ONE set of events for both flights: only a batch that travels as a single tile (nothing in
+       * the other flight) may cut its copy into pieces */
+      if (piped && f.pieces != 1) {
+        snprintf(ctx->last_error, sizeof(ctx->last_error), "internal: a piped decode tile was cut into %u copy pieces", f.pieces);
+        rc = AAD_APIRESULT_NG;
+        break;
+      }
       size_t got = 0;
       bool ok = true;
       for (uint32_t p = 0; ok && p < f.pieces; p++) {
@@ -1654,6 +1677,7 @@ AADApiResult AADHip_ReconstructPlanRun(struct AADHipReconstructPlan *plan, const
   a.partials = device_stats ? plan->d_partials : nullptr;
   a.stats = reinterpret_cast<aad::ErrorStatsRecord *>(device_stats);
   a.write_residual = output_kind == AAD_HIP_RECONSTRUCT_RESIDUAL;
+  a.sequential = ctx->compare_sequential ? 1u : 0u;
   if (a.total_segments > 0x7FFFFFFFull) return AAD_APIRESULT_INVALID_ARGUMENT;
   hipLaunchKernelGGL(aad::compare_segments_kernel, dim3((unsigned)a.total_segments), dim3(aad::kCompareThreads), 0, ctx->stream, a);
   if (device_stats)

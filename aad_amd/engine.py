@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from .capi import (AADApiResult, AADHeaderInfo, ApiError, ERROR_STATS_DTYPE, LANE_MAPPINGS, LANE_STATE_DTYPE,
-                   OPTION_LANE_MAPPING, OPTION_STAGING_THREADS, OPTION_TILE_KBYTES, OPTION_TRIAL_LANES, RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL,
+                   OPTION_COMPARE_ORDER, OPTION_LANE_MAPPING, OPTION_STAGING_THREADS, OPTION_TILE_KBYTES, OPTION_TRIAL_LANES, RECONSTRUCT_DECODED, RECONSTRUCT_RESIDUAL,
                    STREAM_DESC_DTYPE, TRIAL_LANES, load_library, make_parameter)
 
 
@@ -93,6 +93,13 @@ class Engine:
         """Tile budget (KiB) of the host-memory entry points; 0 = built in.  Results do not depend on it."""
         _check("AADHip_ContextSetOption",
                self.lib.AADHip_ContextSetOption(self._ctx, OPTION_TILE_KBYTES, int(kbytes)))
+
+    def set_compare_order(self, sequential=False):
+        """fp64 summation order behind the reconstruction modes' statistics: False = tree on the device with the
+        reference's order taken only next to a rounding boundary of the printed line, True = always the reference's order
+        (bit-identical doubles; AAD_HIP_OPTION_COMPARE_ORDER)"""
+        _check("AADHip_ContextSetOption",
+               self.lib.AADHip_ContextSetOption(self._ctx, OPTION_COMPARE_ORDER, 1 if sequential else 0))
 
     def synchronize(self):
         _check("AADHip_ContextSynchronize", self.lib.AADHip_ContextSynchronize(self._ctx))

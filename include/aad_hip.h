@@ -82,9 +82,15 @@ enum AADHipOption {
   AAD_HIP_OPTION_STAGING_THREADS = 2,
   /* Budget, in KiB, of one tile of the host-memory entry points (input + output bytes that travel
    * together; see DESIGN.md "host-memory path"): 0 = built in (batches up to 16 MiB go as one tile,
-   * larger ones in 8 MiB tiles).  A tile never holds less than one block of one stream.  Default from
+   * larger ones in tiles of about 16 MiB).  A tile never holds less than one block of one stream.  Default from
    * AAD_HIP_TILE_KBYTES.  Results do not depend on it. */
-  AAD_HIP_OPTION_TILE_KBYTES = 3
+  AAD_HIP_OPTION_TILE_KBYTES = 3,
+  /* Order of the fp64 sums behind the reconstruction modes' RMSE / MSD (AADHip_Reconstruct*): 0 = a fixed tree on the
+   * device, with the reference's channel-major sequential order taken per stream only when the tree's result lies so close
+   * to a rounding boundary of the six decimals `aad -c` prints that the order could show (the printed line is the
+   * reference's either way); 1 = always the reference's order (bit-identical doubles, one lane per stream: slow).
+   * Default from AAD_HIP_COMPARE_ORDER (auto | sequential). */
+  AAD_HIP_OPTION_COMPARE_ORDER = 4
 };
 enum AADHipLaneMapping {
   AAD_HIP_LANE_MAPPING_AUTO = 0,      /* by batch size (the default) */

@@ -45,6 +45,7 @@ def test_two_contexts_on_one_device_and_waves(tmp_path):
         assert (enc / (n + ".aad")).read_bytes() == open(os.path.join(FIX, n + ".aad"), "rb").read()
     for n, pcm in inputs.items():
         assert (enc / (n + ".aad")).read_bytes() == ob.encode(pcm, 4, 1024, 48000, False, 2), n
+    assert not [p for p in enc.iterdir() if p.name.endswith(".part")]  # outputs are built as <name>.part and renamed when complete
     subprocess.run([CLI, "-d", "-D", "0,0", "-o", str(dec)] + [str(p) for p in sorted(enc.iterdir())], check=True, env=env, timeout=300)
     for n in ("sin300Hz_mono", "sin300Hz"):
         assert (dec / (n + ".wav")).read_bytes() == open(os.path.join(FIX, n + "_decoded.wav"), "rb").read()

@@ -3,8 +3,10 @@ residual / RMSE-MSD-MaxAE on the device, against the goldens made from the compi
 (tests/golden/cli_modes.json, `aad -r` / `aad -g` / `aad -c`, src/main.c:275-503) and the oracle.
 
 Bar: reconstructed and residual PCM bit-exact.  The three statistics are fp64 sums whose ORDER
-differs from the CLI's channel-major walk (fixed reduction tree on the device), so they are held
-to 1e-12 relative - and to the exact text of the line the CLI printed (six decimals)."""
+differs from the CLI's channel-major walk by default (fixed reduction tree on the device), so they are held
+to 1e-12 relative - and to the exact text of the line the CLI printed (six decimals), which the device
+guarantees by taking the reference's order itself whenever the tree's result lies within the reordering bound
+of a rounding boundary (aad_compare.hip.h); forced, that order gives the oracle's doubles bit for bit."""
 import json
 import os
 import subprocess
@@ -30,6 +32,36 @@ def engine():
     e = Engine(0)
     yield e
     e.close()
+
+
+def test_statistics_in_the_reference_order_are_bit_identical(engine):
+    """AAD_HIP_OPTION_COMPARE_ORDER = sequential: one lane per stream walks the values channel by channel, sample by
+    sample, with separately rounded multiplies and adds - the reference's loop (src/main.c:478-497).  The three
+    doubles must EQUAL the oracle's (==, not a tolerance): this is the path the device takes by itself whenever its
+    tree sum lies close enough to a rounding boundary of the printed six decimals for the order to show, so the
+    printed line is the reference's by construction.  Mono, stereo, 8 channels, lengths from one sample to several
+    blocks, loud noise (large sums) and near-silence (tiny sums)."""
+    engine.set_compare_order(sequential=True)
+    try:
+        rng = np.random.default_rng(31)
+        for ch, bits, trials, ms in ((1, 4, 0, False), (2, 4, 2, False), (2, 3, 0, True), (2, 2, 1, False), (8, 3, 0, False)):
+            lengths = [1, 3, 4, 5, 17, 992, 993, 2500, int(rng.integers(3000, 9000))]
+            pcms = [synth_pcm(1, n, ch, seed=500 + n, kind=["music", "noise", "nyquist"][k % 3])[0] for k, n in enumerate(lengths)]
+            pcms.append((synth_pcm(1, 4000, ch, seed=9)[0] // 4096).astype(np.int16))  # a few LSBs of signal
+            param = make_parameter(ch, bits, 1024, 48000, ms, trials)
+            rec, stats = engine.reconstruct_host(pcms, param, residual=False)
+            for i, pcm in enumerate(pcms):
+                want = ob.error_stats(pcm, rec[i])
+                assert _as_tuple(stats[i]) == want, (ch, bits, trials, ms, len(pcm), _as_tuple(stats[i]), want)
+    finally:
+        engine.set_compare_order(sequential=False)
+    # and the default order prints the same line for the same inputs
+    for ch, bits in ((1, 4), (2, 2)):
+        pcms = [synth_pcm(1, n, ch, seed=600 + n)[0] for n in (5, 992, 4001)]
+        param = make_parameter(ch, bits, 1024, 48000, False, 0)
+        rec, stats = engine.reconstruct_host(pcms, param, residual=False)
+        for i, pcm in enumerate(pcms):
+            assert ob.stats_line(_as_tuple(stats[i])) == ob.stats_line(ob.error_stats(pcm, rec[i]))
 
 
 def _as_tuple(rec):
