@@ -84,6 +84,52 @@ __device__ __forceinline__ void wave_lds_fence()
   __builtin_amdgcn_wave_barrier();
 }
 
+/*
+ * A chunk in two strands.  What a sample needs from the tables - its code's record and the step size at its step index -
+ * depends on the CODES only (idx' = clamp(idx + delta[code]) never sees a sample), so all sixteen lookups of a chunk are
+ * made before its arithmetic starts: walk_chunk (strand 1) fills 48 registers, run_chunk (strand 2) is then pure VALU work
+ * with no LDS wait inside.  The kernel runs strand 1 of chunk j + 1 in front of strand 2 of chunk j, so the lookups'
+ * latency - long with eight waves sharing the CU's LDS - is covered by a whole chunk of arithmetic.  decode_chunk16
+ * interleaves the two sample by sample (the lookup of sample j + 1 behind ~22 instructions of sample j): right for a
+ * lone wave with 64 registers, not for two waves per SIMD with 256.
+ */
+struct ChunkWalk {
+  uint32_t step[kChunk]; /* step << 2 of every sample */
+  u32x2 rec[kChunk];     /* {bias << 29 | delta & 0xFFFF, sm21 << 27} of every sample's code */
+};
+
+template <int BITS>
+__device__ __forceinline__ void walk_chunk(int32_t &idxb, const uint32_t *w, const char *lds, ChunkWalk &W)
+{
+  constexpr int cpw = Pack<BITS>::kCodesPerWord;
+  const uint32_t copy = (threadIdx.x & 3u) << 2;
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int sh = 3, pos = Pack<BITS>::pos(j % cpw);
+    const uint32_t word = w[j / cpw];
+    const uint32_t addr = (pos >= sh ? word >> (pos >= sh ? pos - sh : 0) : word << (sh - pos)) & (((1u << BITS) - 1u) << sh);
+    W.rec[j] = *reinterpret_cast<const u32x2 *>(lds + kLdsDenseCode8Off + addr);
+  });
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    W.step[j] = *reinterpret_cast<const uint32_t *>(lds + kLdsDenseStepOff + (((uint32_t)idxb & 0xFF0u) | copy));
+    idxb = clamp_idx(idxb + (int32_t)(int16_t)W.rec[j].x);
+  });
+}
+
+/* p: the prediction for the chunk's first sample on entry, for the next chunk's on exit */
+template <int BITS, typename Finish>
+__device__ __forceinline__ void run_chunk(Lane &L, const ChunkWalk &W, int32_t &p, int32_t *y, Finish finish)
+{
+  static_for<0, kChunk>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int32_t qd = dense_dequantise(W.step[j], u32x3{W.rec[j].x, 0u, W.rec[j].y});
+    const int32_t yy = clip16(qd + p);
+    p = lms_shift_predict(L, qd, yy);
+    y[j] = finish(yy);
+  });
+}
+
 /* A 16-byte store that does not stay in the L2 (sc1: write-through, the line is dropped - MI355X_MICROARCH.md, "stores of
  * each flavour").  The PCM is written once and never read back; kept in the L2 it evicts the code lines, whose second
  * sector a mono row comes back for one period later (measured: with plain stores every sector visit was a line fill of
@@ -327,22 +373,32 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
   put_granule(1, gn); /* over granule -1: header and lead chunk have been read */
   load_granule(2, gn);
   wave_lds_fence();
-  fetch_raw(s_pos, raw);
-  if (lead) put_pcm(0, pending);
-  wave_lds_fence();
-
-  /* ---- steady state, one iteration per chunk j of every row:
-   *   the last chunk of an input period: granule period + 2 replaces granule period (every row has read its
-   *     bytes of chunk j already - they are in `raw`);
-   *   odd j: output granule (j - 1) / 2 is complete in every row since chunk j - 1 and chunk j is about to write
-   *     over it in some: its pieces are read now and stored behind the chunk's arithmetic;
-   *   decode chunk j; ask for chunk j + 1's code bytes; write chunk j's PCM (that hides the read). */
   const uint32_t ph = (uint32_t)s_pos & 3u;
   int32_t pos = s_pos;
+  fetch_raw(pos, raw);
+  if (lead) put_pcm(0, pending);
+  ChunkWalk wa, wb; /* the tables of the chunk in arithmetic and of the one behind it */
+  int32_t idx_run = L.idxb; /* the step index runs a chunk ahead of the samples */
+  if (0 < full) {
+    uint32_t w[2] = {0, 0};
+    unpack(raw, ph, w);
+    walk_chunk<BITS>(idx_run, w, lds, wa);
+  }
+  pos += T::kCb;
+  fetch_raw(pos, raw); /* chunk 1's code bytes */
+  int32_t p = predict(L);
+  wave_lds_fence();
+
+  /* ---- steady state, one iteration per chunk j of every row (cur: chunk j's tables, `raw`: chunk j + 1's code bytes):
+   *   when chunk j + 2 opens an input period: granule period + 2 replaces granule period (every row has read its bytes
+   *     of chunks <= j + 1 - they are in registers);
+   *   odd j: output granule (j - 1) / 2 is complete in every row since chunk j - 1 and chunk j is about to write over it in
+   *     some: its pieces are read now and stored behind the chunk's arithmetic;
+   *   strand 1 of chunk j + 1, strand 2 of chunk j, ask for chunk j + 2's code bytes, write chunk j's PCM. */
   uint32_t x = T::kPcmBytes;
   int32_t period = 0;
-  for (uint32_t j = 0; j < full_max; j++) {
-    if ((j + 1) % T::kInPeriod == 0) {
+  auto one = [&](uint32_t j, const ChunkWalk &cur, ChunkWalk &next) {
+    if ((j + 2) % T::kInPeriod == 0) {
       put_granule(period + 2, gn);
       period++;
       load_granule(period + 2, gn);
@@ -350,11 +406,14 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
     u32x4 leaving[T::kInst];
     const bool store_now = (j & 1u) != 0;
     if (store_now) read_granule((j - 1) >> 1, leaving);
-    if (j < full) {
+    if (j + 1 < full) {
       uint32_t w[2] = {0, 0};
       unpack(raw, ph, w);
+      walk_chunk<BITS>(idx_run, w, lds, next);
+    }
+    if (j < full) {
       int32_t y[kChunk];
-      decode_chunk16<BITS, kChunk, true>(L, w, lds, y, finish);
+      run_chunk<BITS>(L, cur, p, y, finish);
       pending = pack_chunk_pcm<CHF, false>(y, c);
     }
     if (store_now) write_granule((j - 1) >> 1, leaving);
@@ -364,7 +423,12 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
     if (j < full) put_pcm(x, pending);
     x += T::kPcmBytes;
     wave_lds_fence();
+  };
+  for (uint32_t j = 0; j < full_max; j += 2) {
+    one(j, wa, wb);
+    if (j + 1 < full_max) one(j + 1, wb, wa);
   }
+  L.idxb = idx_run; /* the tail continues where the last walked chunk ended */
   /* what the rows still hold: the granules the loop has not stored */
   for (uint32_t t = full_max >> 1; t <= (full_max >> 1) + 1; t++) {
     u32x4 leaving[T::kInst];
