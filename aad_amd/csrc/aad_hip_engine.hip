@@ -234,17 +234,38 @@ bool pick_quad(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels
   return recurrences <= mapping_limits(bits, channels).encode_quad;
 }
 
+/* lds_pad: dynamic LDS the kernel never touches - it only lowers the number of workgroups a CU holds (see dense_encode_lds_pad) */
 template <int BITS, bool QUAD, bool TRIALS, bool DUAL>
-void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
+void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream, unsigned lds_pad = 0)
 {
   if (a.channels == 1)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD, TRIALS, DUAL>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD, TRIALS, DUAL>), grid, block, lds_pad, stream, a);
   else if (a.channels == 2 && a.mid_side)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD, TRIALS, DUAL>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD, TRIALS, DUAL>), grid, block, lds_pad, stream, a);
   else if (a.channels == 2)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD, TRIALS, DUAL>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD, TRIALS, DUAL>), grid, block, lds_pad, stream, a);
   else if constexpr (!QUAD)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS, false>), grid, block, lds_pad, stream, a);
+}
+
+/* Occupancy cap of the dense 4-bit encoders on chip-filling batches: unused dynamic LDS up to 80 KB per workgroup, so that a
+ * CU holds two workgroups = two waves per SIMD instead of three or four.  These kernels are bound by VALU issue (85 % VALU-
+ * active with two waves as with four), but every resident lane keeps one 128-byte line of PCM and one sector of codes alive
+ * in the L2 between its visits: 8192 lines per CU at four waves per SIMD - 8 MiB per XCD against 4 MiB of L2 - and a line
+ * was fetched 2.2 (mono) / 1.27 (stereo) times; with two waves per SIMD 1.57 / 1.01 times, at the same kernel time
+ * (profiles/r03_encoder_occupancy_cap.txt).  The 3- and 2-bit encoders are VALU-saturated (96-103 % active) and lose 4-6 % of
+ * their time under the same cap for a similar cut in traffic: they keep their occupancy.  AAD_HIP_ENCODE_LDS_PAD (bytes, read
+ * once) overrides the policy for experiments. */
+unsigned dense_encode_lds_pad(uint32_t bits, uint64_t lanes, unsigned static_lds)
+{
+  static const int forced = [] {
+    const char *e = getenv("AAD_HIP_ENCODE_LDS_PAD");
+    return e ? atoi(e) : -1;
+  }();
+  if (forced >= 0) return (unsigned)forced;
+  constexpr unsigned kTarget = 80u << 10; /* two workgroups per CU (160 KB of LDS) */
+  if (bits != 4 || lanes < 65536 || static_lds >= kTarget) return 0;
+  return kTarget - static_lds;
 }
 
 /* On the quad mapping the trial search's probe strand gets lanes of its own ("dual"): one pass of
@@ -281,7 +302,11 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
     else launch_encode_mapped<BITS, false, true, false>(a, grid, block, stream);
   } else {
     if (quad) launch_encode_mapped<BITS, true, false, false>(a, grid, block, stream);
-    else launch_encode_mapped<BITS, false, false, false>(a, grid, block, stream);
+    else {
+      const unsigned static_lds = a.channels == 1 ? (unsigned)aad::kLdsBytesEncoder<BITS, 1, false>
+                                                  : (a.channels == 2 ? (unsigned)aad::kLdsBytesEncoder<BITS, 2, false> : (unsigned)aad::kLdsBytesEncoder<BITS, 0, false>);
+      launch_encode_mapped<BITS, false, false, false>(a, grid, block, stream, wg == 256u ? dense_encode_lds_pad(BITS, lanes, static_lds) : 0u);
+    }
   }
 }
 
