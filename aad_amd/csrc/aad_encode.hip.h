@@ -878,13 +878,26 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
       if constexpr (CHF == 1) {
         /* mono: the samples of TWO chunks (64 bytes) with one group of loads, a pair ahead - a lane that reads
          * 32 bytes per chunk visits every 64-byte sector of its stream three times, a chunk's worth of time apart
-         * (the saturated mono encoder fetched 2.2x its PCM), in pairs twice */
+         * (the saturated mono encoder fetched 2.2x its PCM), in pairs twice.  The 64-byte window starts at the
+         * BLOCK's first sample, not at its first coded one (the four verbatim samples ride in front): on a stream
+         * whose PCM starts on a 64-byte boundary every window is then one whole sector - mono blocks are 63 sectors
+         * long - where a window that starts 8 bytes in straddles two and a 128-byte line is visited three times
+         * instead of twice.  A pair's second chunk ends 8 bytes into the next window: those two dwords always come
+         * from the true next window (load_head: they exist whenever the chunk does), the rest of the prefetch is
+         * clamped to the last window as before. */
         struct PairSamples {
           uint32_t d[16];
-          __device__ __forceinline__ void load(const int16_t *x)
+          __device__ __forceinline__ void load_head(const int16_t *x)
           {
+            const u32x2 q = reinterpret_cast<const U32x2 *>(x)->v;
+            d[0] = q.x; d[1] = q.y;
+          }
+          __device__ __forceinline__ void load_rest(const int16_t *x)
+          {
+            const u32x2 h = reinterpret_cast<const U32x2 *>(x + 4)->v;
+            d[2] = h.x; d[3] = h.y;
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
+            for (int v = 1; v < 4; v++) {
               const u32x4 q = reinterpret_cast<const U32x4 *>(x + 8 * v)->v;
               d[4 * v] = q.x; d[4 * v + 1] = q.y; d[4 * v + 2] = q.z; d[4 * v + 3] = q.w;
             }
@@ -897,28 +910,33 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         };
         const uint32_t pairs = full / 2;
         if (pairs) {
-          PairSamples np;
-          np.load(xp);
+          const int16_t *wp = xp - kTaps; /* the window of pair 0: the block's samples 0 .. 31 */
+          PairSamples cur, np;
+          cur.load_head(wp);
+          cur.load_rest(wp);
           for (uint32_t p = 0; p < pairs; p++, k0 += 2) {
+            np.load_head(wp + 2 * kChunk); /* samples 32 .. 35 of this window's start: the end of the pair's second chunk */
+            if (p + 1 < pairs) wp += (uint64_t)2 * kChunk; /* unconditional prefetch: the last pair re-reads its own window */
+            np.load_rest(wp);
             int32_t xa[kChunk / 2], xb[kChunk / 2];
 #pragma unroll
             for (int j = 0; j < kChunk / 2; j++) {
-              xa[j] = (int32_t)np.d[j];
-              xb[j] = (int32_t)np.d[kChunk / 2 + j];
+              xa[j] = (int32_t)cur.d[2 + j];
+              xb[j] = (int32_t)(j < 6 ? cur.d[10 + j] : np.d[j - 6]);
             }
-            if (p + 1 < pairs) xp += (uint64_t)2 * kChunk; /* unconditional prefetch: the last pair re-reads itself */
-            np.load(xp);
             uint32_t wa[2] = {0, 0}, wb[2] = {0, 0};
             encode_chunk16<BITS, EMIT, true>(L, xa, lds, wa, last_qd, sq);
             encode_chunk16<BITS, EMIT, true>(L, xb, lds, wb, last_qd, sq);
             np.touch();
+#pragma unroll
+            for (int j = 0; j < 16; j++) cur.d[j] = np.d[j];
             if constexpr (kStage) {
               stage.put(k0, wa, c);
               stage.put(k0 + 1, wb, c);
               if ((k0 & 7u) == 6u) stage.flush(body + (uint64_t)(k0 - 6u) * kOutStride, c);
             }
           }
-          xp += (uint64_t)2 * kChunk; /* the last pair was its own prefetch: now the chunk behind it */
+          xp += (uint64_t)pairs * 2 * kChunk; /* the chunk behind the last pair */
           if (k0 < full) next.load(xp, ch, c);
           next.touch();
         }
