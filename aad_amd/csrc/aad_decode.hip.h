@@ -34,6 +34,9 @@ __device__ __forceinline__ int32_t decode_step(S &L, uint32_t code, const char *
  *   A  step index of the next sample; start its step lookup and the record lookup of sample j+2
  *   B  dequantise (mad + shift), reconstruct, LMS, history shift, predict the next sample
  */
+#ifndef AAD_DENSE_REC8
+#define AAD_DENSE_REC8 0 /* experiment: 1 = the per-lane dense decoder takes its code records from the 8-byte table too */
+#endif
 /* REC8: the per-code records come from the 8-byte table (kLdsDenseCode8Off: conflict-free ds_read_b64, one v_mov_b32 for
  * the addend's upper word) instead of the 16-byte one */
 template <int BITS, int N = kChunk, bool REC8 = false, typename S, typename Finish>
@@ -619,7 +622,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         y[1] = y1;
         y[2] = y2;
         y[3] = y3;
-        decode_chunk16<BITS, (int)kLead>(L, w, lds, y + kTaps, finish);
+        decode_chunk16<BITS, (int)kLead, AAD_DENSE_REC8 != 0>(L, w, lds, y + kTaps, finish);
         next.touch();
         if constexpr (CHF == 1) { /* mono: 32 bytes - they wait for the next chunk's 32 (below): a whole 64-byte sector */
           lead_pcm = pack_chunk_pcm<1, false>(y, c);
@@ -670,7 +673,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
         if (k + 1 < full) cp += kStride;
         next.load(cp);
         int32_t y[kChunk];
-        decode_chunk16<BITS>(L, w, lds, y, finish);
+        decode_chunk16<BITS, kChunk, AAD_DENSE_REC8 != 0>(L, w, lds, y, finish);
         next.touch();
         return pack_chunk_pcm<(CHF ? CHF : 1), false>(y, c);
       };
@@ -722,9 +725,9 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
               cur.unpack(2 * i, wa);
               cur.unpack(2 * i + 1, wb);
               int32_t y[kChunk];
-              decode_chunk16<BITS>(L, wa, lds, y, finish);
+              decode_chunk16<BITS, kChunk, AAD_DENSE_REC8 != 0>(L, wa, lds, y, finish);
               const ChunkPcm a = pack_chunk_pcm<1, false>(y, c);
-              decode_chunk16<BITS>(L, wb, lds, y, finish);
+              decode_chunk16<BITS, kChunk, AAD_DENSE_REC8 != 0>(L, wb, lds, y, finish);
               const ChunkPcm b = pack_chunk_pcm<1, false>(y, c);
               emit_pair(a, b);
             });
@@ -755,7 +758,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
               uint32_t w[2] = {0, 0};
               cur.unpack(i, c, w);
               int32_t y[kChunk];
-              decode_chunk16<BITS>(L, w, lds, y, finish);
+              decode_chunk16<BITS, kChunk, AAD_DENSE_REC8 != 0>(L, w, lds, y, finish);
               put_chunk_pcm<2, NT>(op, pack_chunk_pcm<2, false>(y, c), c);
               op += (uint64_t)kChunk * ch;
             });
@@ -808,7 +811,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
       if (k + 1 < full) cp += row; /* unconditional prefetch: the last iteration re-reads its own chunk */
       next.load(cp, unit_stride);
       int32_t y[kChunk];
-      decode_chunk16<BITS>(L, w, lds, y, finish);
+      decode_chunk16<BITS, kChunk, AAD_DENSE_REC8 != 0>(L, w, lds, y, finish);
       next.touch();
       store_chunk_pcm<0, false>(op, y, c, ch);
       op += (uint64_t)kChunk * ch;

@@ -310,30 +310,51 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
   }
 }
 
+/* Occupancy cap of the per-lane dense decoders on chip-filling batches (what is left to them since the sector-tiled kernel:
+ * 3-bit streams, layouts whose PCM is not 16-byte aligned, more than two channels): unused dynamic LDS up to 80 KB per
+ * workgroup = two workgroups per CU = two waves per SIMD.  These kernels wait for memory (56-59 % VALU-active on mono 3-bit
+ * streams), and what they wait for is lines that were evicted between two visits of the same lane: with fewer lanes resident
+ * the L2 keeps more of them.  Mono 3-bit, 524 288 blocks: 2.00 -> 1.72 ms (688 -> 801 Gsamples/s), stereo 3-bit 0.762 -> 0.733 ms;
+ * one wave per SIMD is slower again (1.75 / 0.86 ms); profiles/r03_decoder_occupancy_cap.txt.  AAD_HIP_DECODE_LDS_PAD (bytes, read once) overrides the policy. */
+unsigned dense_decode_lds_pad(uint64_t lanes, uint32_t channels, uint32_t bits)
+{
+  static const int forced = [] {
+    const char *e = getenv("AAD_HIP_DECODE_LDS_PAD");
+    return e ? atoi(e) : -1;
+  }();
+  if (forced >= 0) return (unsigned)forced;
+  constexpr unsigned kTarget = 80u << 10;
+  /* same-box A/B of every geometry on this kernel: mono 4- / 3- / 2-bit +0 / +16 / +7 %, stereo 3- / 2-bit +4 / +2 %, stereo
+   * 4-bit (streamed stores) -4 %: that one keeps its occupancy, and so do the any-channel launches (no change) */
+  const bool gains = channels == 1 || (channels == 2 && bits != 4);
+  return gains && lanes >= 65536 ? kTarget - (unsigned)aad::kLdsBytesDenseDec : 0u;
+}
+
 template <int BITS, bool QUAD>
 void launch_decode_mapped(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
 {
+  const unsigned lds_pad = !QUAD && block.x == 256u ? dense_decode_lds_pad(a.total_blocks * a.channels, a.channels, a.bits) : 0u;
   if (a.channels == 1)
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 1, false, QUAD>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 1, false, QUAD>), grid, block, lds_pad, stream, a);
   else if (a.channels == 2 && a.mid_side) {
     if constexpr (!QUAD && BITS != 3) {
       if (a.stream_stores) {
-        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, false, true>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, false, true>), grid, block, lds_pad, stream, a);
         return;
       }
     }
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, QUAD>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, QUAD>), grid, block, lds_pad, stream, a);
   } else if (a.channels == 2) {
     if constexpr (!QUAD && BITS != 3) {
       if (a.stream_stores) {
-        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, false, true>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, false, true>), grid, block, lds_pad, stream, a);
         return;
       }
     }
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, QUAD>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, QUAD>), grid, block, lds_pad, stream, a);
   }
   else if constexpr (!QUAD)
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false, false>), grid, block, lds_pad, stream, a);
 }
 
 /* Quad decode runs its two strands on different lanes (aad_decode_split.hip.h) unless
