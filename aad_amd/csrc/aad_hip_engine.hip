@@ -364,8 +364,18 @@ constexpr uint64_t kMaxResidualBytes = 1ull << 30;
 
 /* Decode mapping by batch size: see mapping_limits.  The context option forces one. */
 enum class DecodeMapping { Dense, QuadFused, QuadSplit };
-/* dense batches at and beyond this many recurrences take the sector-tiled kernel where it applies (aad_decode_tiled.hip.h) */
-constexpr uint64_t kTiledDecodeMin = 65536;
+/* Dense batches at and beyond this many recurrences take the sector-tiled kernel where it applies (aad_decode_tiled.hip.h).
+ * Measured against the per-lane kernel (with its own occupancy cap) on one-block streams, same box, tools/saturated_probe.py
+ * (profiles/r03_tiled_decode_crossover.txt): mono 4-bit wins from 65 536 blocks on (one wave per SIMD: 0.156 vs 0.198 ms;
+ * 0.43 vs 0.48 ms at 196 608; 1.10 vs 1.29 ms at 524 288), stereo 4-bit from ~393 216 recurrences (0.42 vs 0.45 ms; equal at
+ * 262 144, the per-lane kernel ahead below).  On 2-bit streams - eight PCM bytes per code byte: the code side it saves is small -
+ * the tiled kernel moves 1.02x the algorithmic bytes instead of 1.5x but takes 3-7 % longer: "auto" keeps the per-lane kernel
+ * there, AAD_HIP_LANE_MAPPING_DENSE_TILED selects the tiled one at any size. */
+uint64_t tiled_decode_min(uint32_t bits, uint32_t channels)
+{
+  if (bits == 4) return channels == 1 ? 65536u : 393216u;
+  return ~0ull;
+}
 
 DecodeMapping pick_decode_mapping(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels, uint32_t bits)
 {
@@ -407,7 +417,7 @@ void launch_decode(const AADHipContext *ctx, const aad::DecodeArgs &a, int32_t *
   const DecodeMapping pick = pick_decode_mapping(ctx, lanes, a.channels, BITS);
   /* dense: the sector-tiled kernel for chip-filling batches (or when the option asks for it), where it applies */
   if (pick == DecodeMapping::Dense && ctx->lane_mapping != AAD_HIP_LANE_MAPPING_DENSE &&
-      (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_DENSE_TILED || lanes >= kTiledDecodeMin) && aad::launch_decode_tiled(a, stream))
+      (ctx->lane_mapping == AAD_HIP_LANE_MAPPING_DENSE_TILED || lanes >= tiled_decode_min(BITS, a.channels)) && aad::launch_decode_tiled(a, stream))
     return;
   const bool quad = pick == DecodeMapping::QuadFused || (pick == DecodeMapping::QuadSplit && ctx->lane_mapping == AAD_HIP_LANE_MAPPING_QUAD);
   const uint64_t threads = quad ? lanes * 4 : lanes;
