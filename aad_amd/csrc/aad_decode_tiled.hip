@@ -11,7 +11,9 @@ bool decode_tiled_applicable(const DecodeArgs &a)
   if (a.channels < 1 || a.channels > 2) return false;
   if (a.bits != 4 && a.bits != 2) return false;
   if (!a.pcm_aligned16) return false;
-  if (((uint64_t)a.samples_per_block * a.channels * 2u) % 16u != 0) return false; /* every block of a stream starts on a piece boundary */
+  /* every block of a stream starts on a piece boundary: the block length in PCM bytes is a multiple of 16 (mono 2-bit
+   * blocks of 1024 bytes hold 4028 samples = 8056 bytes: not) - or no stream has a second block */
+  if (((uint64_t)a.samples_per_block * a.channels * 2u) % 16u != 0 && a.total_blocks > a.num_streams) return false;
   if ((reinterpret_cast<uintptr_t>(a.pcm) & 15u) != 0) return false;
   return true;
 }

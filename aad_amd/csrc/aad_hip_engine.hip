@@ -368,13 +368,13 @@ enum class DecodeMapping { Dense, QuadFused, QuadSplit };
  * Measured against the per-lane kernel (with its own occupancy cap) on one-block streams, same box, tools/saturated_probe.py
  * (profiles/r03_tiled_decode_crossover.txt): mono 4-bit wins from 65 536 blocks on (one wave per SIMD: 0.156 vs 0.198 ms;
  * 0.43 vs 0.48 ms at 196 608; 1.10 vs 1.29 ms at 524 288), stereo 4-bit from ~393 216 recurrences (0.42 vs 0.45 ms; equal at
- * 262 144, the per-lane kernel ahead below).  On 2-bit streams - eight PCM bytes per code byte: the code side it saves is small -
- * the tiled kernel moves 1.02x the algorithmic bytes instead of 1.5x but takes 3-7 % longer: "auto" keeps the per-lane kernel
- * there, AAD_HIP_LANE_MAPPING_DENSE_TILED selects the tiled one at any size. */
+ * 262 144, the per-lane kernel ahead below); mono 2-bit like mono 4-bit (2.15 vs 2.52 ms at 524 288 blocks).  On STEREO 2-bit
+ * streams the tiled kernel moves 1.02x the algorithmic bytes instead of 1.35x but takes 3-7 % longer (1.04-1.08 vs 1.01-1.02 ms):
+ * "auto" keeps the per-lane kernel there, AAD_HIP_LANE_MAPPING_DENSE_TILED selects the tiled one at any size. */
 uint64_t tiled_decode_min(uint32_t bits, uint32_t channels)
 {
-  if (bits == 4) return channels == 1 ? 65536u : 393216u;
-  return ~0ull;
+  if (channels == 1) return 65536u;
+  return bits == 4 ? 393216u : ~0ull;
 }
 
 DecodeMapping pick_decode_mapping(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels, uint32_t bits)
