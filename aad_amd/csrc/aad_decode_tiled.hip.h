@@ -76,14 +76,6 @@ static_assert(sizeof(RowMeta) == 32, "RowMeta is one 32-byte LDS record");
 
 constexpr int kLdsTileOff = (kLdsBytesDenseDec + 15) & ~15;
 
-/* the compiler sees one thread: tell it that LDS written here is read by OTHER lanes of the wave (no instruction:
- * the LDS serves a wave's accesses in order) */
-__device__ __forceinline__ void wave_lds_fence()
-{
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
 /*
  * A chunk in two strands.  What a sample needs from the tables - its code's record and the step size at its step index -
  * depends on the CODES only (idx' = clamp(idx + delta[code]) never sees a sample), so all sixteen lookups of a chunk are
@@ -128,22 +120,6 @@ __device__ __forceinline__ void run_chunk(Lane &L, const ChunkWalk &W, int32_t &
     p = lms_shift_predict(L, qd, yy);
     y[j] = finish(yy);
   });
-}
-
-/* A 16-byte store that does not stay in the L2 (sc1: write-through, the line is dropped - MI355X_MICROARCH.md, "stores of
- * each flavour").  The PCM is written once and never read back; kept in the L2 it evicts the code lines, whose second
- * sector a mono row comes back for one period later (measured: with plain stores every sector visit was a line fill of
- * its own - FETCH_SIZE x 2 = 2.0x the code bytes - and the half-written PCM lines left the L2 as 1.27x their bytes). */
-#ifndef AAD_TILED_STORE_SC1
-#define AAD_TILED_STORE_SC1 1
-#endif
-__device__ __forceinline__ void store_through(uint64_t address, const u32x4 &v)
-{
-#if AAD_TILED_STORE_SC1
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(address), "v"(v) : "memory");
-#else
-  *reinterpret_cast<u32x4 *>(address) = v;
-#endif
 }
 
 template <int BITS, int CHF, bool MS>

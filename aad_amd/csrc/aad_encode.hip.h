@@ -320,6 +320,7 @@ struct EncodeArgs {
    * (reference src/aad_encoder.c:503-512), so a stream continued from carried state has to bring
    * that block along. */
   uint32_t lead_frames;
+  uint32_t ring_ok; /* every image starts on a 64-byte boundary relative to `data` (host-checked): the dense 4- / 2-bit encoders may use ByteRing */
   /* dual trial search (encode_block_dual): three block-sized slots per stream, device memory of the context */
   uint8_t *trial_scratch;
   uint32_t trial_slot_bytes;
@@ -422,7 +423,7 @@ __device__ __forceinline__ void store_be16(uint8_t *p, uint32_t v)
 /* defer3: leave the last three bytes (low byte of weight 3, history 3) unwritten and return them, lowest
  * address in the low byte - the dense stereo encoder writes them with the first code bytes, which
  * share their 64-byte granule (see run_block) */
-__device__ __forceinline__ uint32_t write_block_header(Lane &L, uint8_t *p, bool do_store, bool defer3 = false)
+__device__ __forceinline__ uint32_t write_block_header(Lane &L, uint8_t *p, bool do_store, bool defer3 = false, uint32_t *words = nullptr)
 {
   auto wabs = [](int32_t w) { const int32_t m = w >> 31; return (int32_t)(((uint32_t)w ^ (uint32_t)m) - (uint32_t)m); };
   const int32_t maxabs = max(max(max(wabs(L.w0), wabs(L.w1)), max(wabs(L.w2), wabs(L.w3))), 0);
@@ -434,6 +435,15 @@ __device__ __forceinline__ uint32_t write_block_header(Lane &L, uint8_t *p, bool
   L.w3 &= mask;
   const uint32_t w3 = (uint32_t)(L.w3 >> shift), h3 = (uint32_t)L.h3;
   const uint32_t last3 = (w3 & 0xFFu) | (((h3 >> 8) & 0xFFu) << 8) | ((h3 & 0xFFu) << 16);
+  if (words != nullptr) { /* the eighteen bytes in memory order, for the byte ring */
+    auto two_ = [](uint32_t first, uint32_t second) { return perm(second, first, 0x04050001); };
+    const uint32_t f0_ = ((((uint32_t)(L.idxb - kIdxBias)) << 4) & 0xFFFFu) | ((uint32_t)shift & 0xFu);
+    words[0] = two_(f0_, (uint32_t)(L.w0 >> shift));
+    words[1] = two_((uint32_t)L.h0, (uint32_t)(L.w1 >> shift));
+    words[2] = two_((uint32_t)L.h1, (uint32_t)(L.w2 >> shift));
+    words[3] = two_((uint32_t)L.h2, w3);
+    words[4] = ((h3 >> 8) & 0xFFu) | ((h3 & 0xFFu) << 8);
+  }
   if (!do_store) return last3;
   /* nine big-endian 16-bit fields, stored two to a dword (any alignment: images start on 16-byte
    * boundaries at best, headers never do) instead of byte by byte */
@@ -611,12 +621,184 @@ struct CodeStage {
     }
   }
 };
+/*
+ * Per-row byte ring (round 3; dense encoders, the encode pass): the image of a row - a mono lane's stream, or a stereo pair's - is
+ * ONE byte stream (file header, then per block: header, packed codes, tail units), and every 64-byte sector of it is stored
+ * exactly once, whole, the moment the stream crosses into the next sector.  Before, a lane stored its codes in 64-byte bursts that
+ * start where the codes start (49 / 67 bytes into an image): every sector was written in two pieces eight chunks apart, and the
+ * encoders wrote 1.3-2.1x their code bytes (profiles/r03_saturated_geometries_pmc.txt); headers and tails went out in small
+ * stores of their own.
+ *   The ring is 128 bytes of LDS per row in IMAGE alignment (ring offset = image offset & 127; images start on 64-byte boundaries:
+ * host-checked).  A chunk's bytes arrive as one or two dwords in memory order at a byte position that is not dword aligned, so
+ * they are merged with a carry of up to three bytes (three v_perm_b32 whose selectors depend on the position's low two bits only -
+ * constant within a block for 8- and 4-byte pieces) and written as ALIGNED dwords (unaligned LDS accesses cost 65 cycles per
+ * instruction on gfx950: tools/microbench/ubench_lds_unaligned.hip).  A stereo pair shares a ring: lane c appends its half of
+ * the pair's interleaved bytes behind lane c - 1's, the carry travels from lane 0 to lane 1 within a chunk and back to lane 0 for
+ * the next (one DPP swap).  Headers and tail units (a few bytes per block) are written byte by byte around a hand-over of the
+ * carry through the ring.  When an append moves the stream into the next sector the row's lanes read the finished one back
+ * (ds_read_b128) and store it with 16-byte stores at its own address: mono 4 per lane, stereo 2 per lane.
+ */
+struct RingSelectors { uint32_t take, shift, keep; }; /* v_perm_b32 selectors for a byte phase (position & 3) */
+__device__ __forceinline__ RingSelectors ring_selectors(uint32_t s)
+{
+  RingSelectors r;
+  const uint32_t low = (1u << (8u * s)) - 1u; /* the low s bytes */
+  r.shift = 0x07060504u - 0x01010101u * s;   /* bytes 4 - s .. 7 - s of {hi : lo}: the next aligned dword of a stream that sits s bytes in */
+  r.take = (r.shift & ~low) | (0x03020100u & low); /* s bytes of the carry (lo), then 4 - s bytes of the new dword (hi) */
+  r.keep = ((0x03020100u + 0x01010101u * (4u - s)) & low) | (0x0c0c0c0cu & ~low); /* the last s bytes of a dword, rest zero: the new carry */
+  return r;
+}
+
+template <int CHF>
+struct ByteRing {
+  static constexpr uint32_t kPitch = 144; /* 128 bytes + 16: rows a power of two apart would put every row on the same banks */
+  char *row;      /* this row's ring */
+  uint8_t *image; /* the stream's image in memory (64-byte aligned) */
+  uint32_t pos;   /* bytes of the image appended so far, by the whole row */
+  uint32_t carry; /* the bytes in front of this lane's next append that do not fill a dword yet (low bytes), see append() */
+  uint32_t limit; /* bytes of the image that may be written (data_size) */
+  uint32_t c;     /* this lane's channel */
+
+  __device__ __forceinline__ void init(char *area, uint32_t row_index, uint8_t *img, uint32_t data_size, uint32_t channel)
+  {
+    row = area + row_index * kPitch;
+    image = img;
+    pos = 0;
+    carry = 0;
+    limit = data_size;
+    c = channel;
+  }
+  __device__ __forceinline__ char *at(uint32_t p) const { return row + (p & 127u); }
+
+  /* the sector that ends where the stream now stands: whole, to memory (or byte by byte where the image ends inside it) */
+  __device__ __forceinline__ void flush_sector(uint32_t sector_start)
+  {
+    wave_lds_fence();
+    const char *from = row + (sector_start & 64u);
+    uint8_t *to = image + sector_start;
+    if (sector_start + 64u <= limit) {
+      constexpr int kPieces = 4 / CHF; /* 16-byte pieces per lane */
+#pragma unroll
+      for (int i = 0; i < kPieces; i++) {
+        /* stereo: the two lanes of a pair store adjacent pieces in one instruction (32 contiguous bytes), the other half next */
+        const uint32_t o = 16u * (CHF == 2 ? 2u * i + c : (uint32_t)i);
+        /* stereo: the pair's two lanes store 32 contiguous bytes per instruction - written through (sc1), the sector reaches
+         * memory as its 64 bytes (1.00x; 1.28x with plain stores: half-written lines).  Mono: one lane, four 16-byte stores -
+         * written through they are four partial writes (1.97x); plain stores merge in the L2 (1.06x). */
+        if (CHF == 2) store_through(reinterpret_cast<uint64_t>(to + o), *reinterpret_cast<const u32x4 *>(from + o));
+        else *reinterpret_cast<u32x4 *>(to + o) = *reinterpret_cast<const u32x4 *>(from + o);
+      }
+    } else if (c == 0) { /* the caller's buffer ends inside this sector: only the bytes it holds */
+      for (uint32_t o = 0; sector_start + o < limit && o < 64u; o++) to[o] = (uint8_t)from[o];
+    }
+    wave_lds_fence();
+  }
+  /* `bytes` more bytes have been written behind pos by the row's lanes: move on, store what got complete */
+  __device__ __forceinline__ void advance(uint32_t bytes)
+  {
+    const uint32_t before = pos;
+    pos += bytes;
+    if (((before ^ pos) & ~63u) != 0) flush_sector(before & ~63u); /* appends are shorter than a sector: at most one boundary */
+  }
+
+  /* n_bytes (8 or 4, the same on both lanes of a pair) of this lane in memory order in d0 (and d1): behind the bytes of the
+   * lanes before it.  sel: ring_selectors of (pos + c * n_bytes) & 3 - the caller keeps them per block. */
+  template <int N>
+  __device__ __forceinline__ void append(uint32_t d0, uint32_t d1, const RingSelectors &sel)
+  {
+    static_assert(N == 8 || N == 4, "whole dwords");
+    /* this lane's carry-in: mono - its own carry; stereo - lane 0 takes lane 1's carry of the previous chunk, lane 1 takes
+     * lane 0's of this one (same byte phase on both lanes: their pieces are whole dwords long) */
+    const uint32_t out = N == 8 ? perm(0u, d1, sel.keep) : perm(0u, d0, sel.keep);
+    uint32_t in = carry;
+    if (CHF == 2) in = pair_swap<false>(c ? carry : out, c);
+    const uint32_t p = pos + c * N;
+    const uint32_t m0 = perm(d0, in, sel.take);
+    *reinterpret_cast<uint32_t *>(at(p & ~3u)) = m0;
+    if (N == 8) *reinterpret_cast<uint32_t *>(at((p & ~3u) + 4u)) = perm(d1, d0, sel.shift);
+    carry = out;
+    advance(N * CHF);
+  }
+
+  /* hand the carry over to the ring (before bytes are written one by one) ... */
+  __device__ __forceinline__ void carry_to_ring()
+  {
+    /* the partial dword in front of pos: in a pair it is lane 1's carry (the last piece of a chunk is lane 1's) */
+    if ((pos & 3u) != 0 && c == (uint32_t)(CHF - 1)) *reinterpret_cast<uint32_t *>(at(pos & ~3u)) = carry;
+    wave_lds_fence();
+  }
+  /* ... and take it back (before the next append): the lane whose carry the next append reads first */
+  __device__ __forceinline__ void carry_from_ring()
+  {
+    wave_lds_fence();
+    const uint32_t s = pos & 3u;
+    const uint32_t word = *reinterpret_cast<const uint32_t *>(at(pos & ~3u));
+    carry = s ? word & ((1u << (8u * s)) - 1u) : 0u;
+  }
+  __device__ __forceinline__ void put_byte(uint32_t p, uint32_t value) { *reinterpret_cast<uint8_t *>(at(p)) = (uint8_t)value; }
+
+  /* the end of the stream: what the last sector holds, in the fewest naturally aligned stores (16, 8, 4, 2, 1 bytes: thirty-one
+   * single bytes were thirty-one requests the L2 did not always merge) */
+  __device__ __forceinline__ void finish()
+  {
+    carry_to_ring();
+    if (c != 0) return;
+    const uint32_t start = pos & ~63u;
+    uint32_t end = pos < limit ? pos : limit;
+    uint32_t o = start;
+    for (; o + 16u <= end; o += 16u) *reinterpret_cast<u32x4 *>(image + o) = *reinterpret_cast<const u32x4 *>(at(o));
+    if (o + 8u <= end) {
+      *reinterpret_cast<u32x2 *>(image + o) = *reinterpret_cast<const u32x2 *>(at(o));
+      o += 8u;
+    }
+    if (o + 4u <= end) {
+      *reinterpret_cast<uint32_t *>(image + o) = *reinterpret_cast<const uint32_t *>(at(o));
+      o += 4u;
+    }
+    if (o + 2u <= end) {
+      *reinterpret_cast<uint16_t *>(image + o) = *reinterpret_cast<const uint16_t *>(at(o));
+      o += 2u;
+    }
+    if (o < end) image[o] = (uint8_t)*at(o);
+  }
+};
+
 /* which dense encoders stage their codes, where the staging area starts in their LDS block, and its size */
 template <int BITS, int CHF, bool QUAD>
 constexpr bool kStagedCodes = !QUAD && (CHF == 1 || (CHF == 2 && BITS != 4));
 constexpr int kLdsCodeStageOff = (kLdsBytesQuadEnc + 15) & ~15;
 template <int BITS, int CHF, bool QUAD>
 constexpr int kLdsBytesEncoder = kStagedCodes<BITS, CHF, QUAD> ? kLdsCodeStageOff + 4 * 8 * 64 * (BITS == 2 ? 4 : 8) : kLdsBytesQuadEnc;
+/* the instantiations that move their output through ByteRing: dense, mono / stereo, 4- and 2-bit codes (pieces of whole dwords) */
+template <int BITS, int CHF, bool QUAD>
+constexpr bool kRingable = !QUAD && (CHF == 1 || CHF == 2) && (BITS == 4 || BITS == 2);
+template <int CHF>
+constexpr int kLdsRingBytes = 4 * (64 / (CHF ? CHF : 1)) * 144; /* four waves of rows */
+template <int BITS, int CHF, bool QUAD, bool RING>
+constexpr int kLdsBytesEncoderRing = RING ? kLdsCodeStageOff + kLdsRingBytes<CHF> : kLdsBytesEncoder<BITS, CHF, QUAD>;
+
+/* the lane's bytes of a chunk in memory order (mono: its 8 / 4 code bytes; stereo: its half of the pair's interleaved bytes,
+ * as store_chunk_codes / CodeStage::put build them): 4-bit -> d0, d1; 2-bit -> d0 */
+template <int BITS, int CHF>
+__device__ __forceinline__ void chunk_bytes(const uint32_t *w, uint32_t c, uint32_t &d0, uint32_t &d1)
+{
+  static_assert(BITS == 4 || BITS == 2, "pieces of whole dwords");
+  d1 = 0;
+  if (CHF == 1) {
+    d0 = perm(0, w[0], 0x00010203);
+    if (BITS == 4) d1 = perm(0, w[1], 0x00010203);
+  } else if (BITS == 2) { /* pair: a0 b0 a1 b1 | a2 b2 a3 b3 ; lane c holds dword c */
+    const uint32_t other = pair_swap<false>(w[0], c);
+    const uint32_t A = c ? other : w[0], B = c ? w[0] : other;
+    d0 = perm(A, B, c ? 0x00040105u : 0x02060307u);
+  } else { /* lane 0 holds the first half of the pair's sixteen bytes (word 0 of both channels), lane 1 the second */
+    const uint32_t send = c ? w[0] : w[1], keep = c ? w[1] : w[0];
+    const uint32_t recv = pair_swap<false>(send, c);
+    const uint32_t A = c ? recv : keep, B = c ? keep : recv;
+    d0 = perm(A, B, 0x02060307);
+    d1 = perm(A, B, 0x00040105);
+  }
+}
 
 /* the dense stereo 4-bit encode pass stores its codes four chunks at a time (run_block) */
 template <int BITS, int CHF, bool EMIT>
@@ -635,12 +817,18 @@ constexpr bool kBurstStores = EMIT && CHF == 2 && BITS == 4;
  * mapping only; `pad` then says per lane whether the pass ends like an encode pass (zero padding up to
  * the last whole unit) or like a measurement (at the last real sample) - the sum covers real samples
  * either way. */
-template <int BITS, int CHF, bool MS, bool QUAD, int PASS, typename S>
+/* RING: the encode pass appends its bytes to the row's ByteRing (`ring`) instead of storing them under `body` */
+template <int BITS, int CHF, bool MS, bool QUAD, int PASS, bool RING = false, typename S>
 __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, uint64_t first, uint32_t n, uint32_t ch,
                                              uint32_t c, bool writer, uint8_t *body, const char *lds, int32_t &last_qd,
-                                             bool defer3 = false, uint32_t deferred = 0, bool pad = true)
+                                             bool defer3 = false, uint32_t deferred = 0, bool pad = true,
+                                             ByteRing<(CHF ? CHF : 1)> *ring = nullptr)
 {
   constexpr bool EMIT = PASS != kPassRmse;
+  static_assert(!RING || (EMIT && kRingable<BITS, CHF, QUAD>), "the byte ring serves the dense 4- / 2-bit encode passes");
+  constexpr int kPiece = BITS == 4 ? 8 : 4; /* RING: bytes of a chunk per lane */
+  RingSelectors ring_sel = {0, 0, 0};
+  if constexpr (RING) ring_sel = ring_selectors((ring->pos + c * kPiece) & 3u);
   static_assert(PASS != kPassBoth || QUAD, "measurement and encode in one pass: quad mapping only");
   constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
   const uint32_t unit_stride = UB * ch;
@@ -806,6 +994,25 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         if (k + 1 < full) one(k + 1, xn, x);
       }
       done = full * kChunk;
+    } else if constexpr (RING && CHF == 2 && BITS == 4) {
+      /* dense stereo 4-bit through the byte ring: the same chunk body as the burst path below, the lane's eight bytes appended */
+      constexpr bool PK = !MS;
+      constexpr int kN = PK ? kChunk / 2 : kChunk;
+      const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
+      for (uint32_t k = 0; k < full; k++) {
+        int32_t x[kN];
+#pragma unroll
+        for (int j = 0; j < kN; j++) x[j] = PK ? (int32_t)next.pair(j, pair_sel) : next.get(j, c);
+        if (k + 1 < full) xp += (uint64_t)kChunk * ch;
+        next.load(xp, ch, c);
+        uint32_t w[2] = {0, 0};
+        encode_chunk16<BITS, EMIT, PK>(L, x, lds, w, last_qd, sq);
+        next.touch();
+        uint32_t d0, d1;
+        chunk_bytes<BITS, CHF>(w, c, d0, d1);
+        ring->template append<8>(d0, d1, ring_sel);
+      }
+      done = full * kChunk;
     } else if constexpr (kBurstStores<BITS, CHF, EMIT>) {
       /* Dense stereo 4-bit, the saturated BASELINE shape.  A pair of lanes produces 16 code bytes per
        * chunk; stored chunk by chunk, the four stores that fill a 64-byte granule are a chunk's worth of
@@ -871,7 +1078,7 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
       constexpr bool PK = CHF != 0 && !MS;
       constexpr int kN = PK ? kChunk / 2 : kChunk;
       const uint32_t pair_sel = c ? 0x07060302u : 0x05040100u;
-      constexpr bool kStage = EMIT && kStagedCodes<BITS, CHF, false>; /* the codes of eight chunks leave together (CodeStage) */
+      constexpr bool kStage = EMIT && !RING && kStagedCodes<BITS, CHF, false>; /* the codes of eight chunks leave together (CodeStage) */
       CodeStage<BITS, kStage ? CHF : 1> stage;
       if constexpr (kStage) stage.init(const_cast<char *>(lds) + kLdsCodeStageOff);
       uint32_t k0 = 0;
@@ -930,6 +1137,15 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
             np.touch();
 #pragma unroll
             for (int j = 0; j < 16; j++) cur.d[j] = np.d[j];
+            if constexpr (RING && BITS == 2) { /* the pair's two dwords in one append: one carry, one boundary test */
+              ring->template append<8>(perm(0, wa[0], 0x00010203), perm(0, wb[0], 0x00010203), ring_sel);
+            } else if constexpr (RING) {
+              uint32_t d0, d1;
+              chunk_bytes<BITS, CHF>(wa, c, d0, d1);
+              ring->template append<kPiece>(d0, d1, ring_sel);
+              chunk_bytes<BITS, CHF>(wb, c, d0, d1);
+              ring->template append<kPiece>(d0, d1, ring_sel);
+            }
             if constexpr (kStage) {
               stage.put(k0, wa, c);
               stage.put(k0 + 1, wb, c);
@@ -939,6 +1155,29 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
           xp += (uint64_t)pairs * 2 * kChunk; /* the chunk behind the last pair */
           if (k0 < full) next.load(xp, ch, c);
           next.touch();
+        }
+      }
+      if constexpr (RING && CHF == 2 && BITS == 2) {
+        /* stereo 2-bit through the ring: two chunks per append.  A pair's sixteen bytes of two chunks are chunk k's eight
+         * (lane 0 appends them) and chunk k + 1's (lane 1): each lane needs the other channel's word of ITS chunk - one swap,
+         * then the same interleave as a 4-bit chunk (chunk_bytes<4, 2> with w = {word of chunk k, word of chunk k + 1}). */
+        for (; k0 + 2 <= full; k0 += 2) {
+          uint32_t w2[2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            int32_t x[kN];
+#pragma unroll
+            for (int j = 0; j < kN; j++) x[j] = PK ? (int32_t)next.pair(j, pair_sel) : next.get(j, c);
+            if (k0 + h + 1 < full) xp += (uint64_t)kChunk * ch;
+            next.load(xp, ch, c);
+            uint32_t w[2] = {0, 0};
+            encode_chunk16<BITS, EMIT, PK>(L, x, lds, w, last_qd, sq);
+            next.touch();
+            w2[h] = w[0];
+          }
+          uint32_t d0, d1;
+          chunk_bytes<4, 2>(w2, c, d0, d1);
+          ring->template append<8>(d0, d1, ring_sel);
         }
       }
       for (uint32_t k = k0; k < full; k++) {
@@ -951,7 +1190,11 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         uint32_t w[2] = {0, 0};
         encode_chunk16<BITS, EMIT, PK>(L, x, lds, w, last_qd, sq);
         next.touch();
-        if constexpr (kStage) {
+        if constexpr (RING) {
+          uint32_t d0, d1;
+          chunk_bytes<BITS, CHF>(w, c, d0, d1);
+          ring->template append<kPiece>(d0, d1, ring_sel);
+        } else if constexpr (kStage) {
           stage.put(k, w, c);
           if ((k & 7u) == 7u) stage.flush(body + (uint64_t)(k - 7u) * kOutStride * ch, c);
         } else if (EMIT) {
@@ -979,7 +1222,23 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
     }
   }
 
-  if constexpr (kBurstStores<BITS, CHF, EMIT> && !QUAD) {
+  if constexpr (RING) {
+    /* tail units through the ring, byte by byte: samples past n are zero padding - reference :592-593 */
+    ring->carry_to_ring();
+    uint32_t units = 0;
+    for (uint32_t i = done; i < coded; i += US, units++) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < US; k++) {
+        const int32_t x = i + k < coded ? src.at(first + kTaps + i + k) : 0;
+        acc = (acc << BITS) | encode_step<BITS>(L, x, lds, last_qd);
+      }
+#pragma unroll
+      for (int k = 0; k < UB; k++) ring->put_byte(ring->pos + units * unit_stride + c * UB + k, acc >> (8 * (UB - 1 - k)));
+    }
+    ring->advance(units * unit_stride);
+    ring->carry_from_ring();
+  } else if constexpr (kBurstStores<BITS, CHF, EMIT> && !QUAD) {
     /* tail units (one byte per lane and unit, at most seven) are collected and stored with what the
      * chunk loop left over, back to back: the block's last granule is written once, not unit by unit */
     uint64_t tail = 0;
@@ -1292,12 +1551,13 @@ __device__ __forceinline__ void encode_block_dual(Lane &F, int32_t &last_qd, con
  * Stream-parallel encode (reference src/aad_encoder.c:814-891 with EncodeBlock :565-727 and the
  * optional trial search :470-562 inlined).  lane = (stream, channel).
  */
-template <int BITS, int CHF, bool MS, bool QUAD, bool TRIALS, bool DUAL = false>
+template <int BITS, int CHF, bool MS, bool QUAD, bool TRIALS, bool DUAL = false, bool RING = false>
 __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytesEncoder<BITS, CHF, QUAD>]; /* dense and quad encoders share the four-copy wide table; mono dense: + code staging */
+  static_assert(!RING || kRingable<BITS, CHF, QUAD>, "the byte ring: dense mono / stereo encoders, 4- and 2-bit codes");
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytesEncoderRing<BITS, CHF, QUAD, RING>]; /* dense and quad encoders share the wide table; dense: + code staging or the rows' byte rings */
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, true, kWideStepShift, true>(lds);
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
@@ -1334,7 +1594,24 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
     last_qd = r.quantize_error;
   }
 
-  if (c == 0 && writer) { /* file header - reference src/aad_encoder.c:190-214 */
+  ByteRing<(CHF ? CHF : 1)> ring;
+  if constexpr (RING) {
+    ring.init(lds + kLdsCodeStageOff + (threadIdx.x >> 6) * (kLdsRingBytes<CHF> / 4), (threadIdx.x & 63u) / CHF, out,
+              sd.data_size > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sd.data_size, c);
+    /* file header - reference src/aad_encoder.c:190-214 - through the ring, byte by byte (once per stream) */
+    const uint32_t encoded = total - a.lead_frames;
+    if (c == 0) {
+#pragma unroll
+      for (uint32_t i = 0; i < (uint32_t)kFileHeaderBytes; i++) {
+        uint32_t b = a.header_template[i];
+        if (i >= 14 && i < 18) b = (encoded >> (8u * (17u - i))) & 0xFFu; /* the sample count, big-endian in bytes 14..17 */
+        ring.put_byte(i, b);
+      }
+    }
+    ring.advance(kFileHeaderBytes);
+    ring.carry_from_ring();
+  }
+  if (!RING && c == 0 && writer) { /* file header - reference src/aad_encoder.c:190-214 */
     const uint32_t encoded = total - a.lead_frames;
     /* 31 bytes as seven dwords and three bytes; the sample count is big-endian in bytes 14..17 */
     const uint32_t *t = reinterpret_cast<const uint32_t *>(a.header_template);
@@ -1368,6 +1645,20 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
     uint8_t *body = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch;
     /* dense stereo 4-bit: code bytes 3 bytes into a 64-byte granule - the channel-1 lane holds the
      * header's last three bytes back for the first burst of code bytes (run_block) */
+    if constexpr (RING) {
+      /* the block header's eighteen bytes per channel behind what the row has written so far, then the codes */
+      uint32_t words[5];
+      (void)write_block_header(F, nullptr, false, false, words);
+      ring.carry_to_ring();
+#pragma unroll
+      for (uint32_t i = 0; i < (uint32_t)kBlockHeaderBytesPerCh; i++)
+        ring.put_byte(ring.pos + c * kBlockHeaderBytesPerCh + i, words[i >> 2] >> (8u * (i & 3u)));
+      ring.advance(kBlockHeaderBytesPerCh * (CHF ? CHF : 1));
+      ring.carry_from_ring();
+      L = F;
+      (void)run_block<BITS, CHF, MS, QUAD, kPassEncode, true>(L, src, first, n, ch, c, writer, body, lds, last_qd, false, 0, true, &ring);
+      F = L;
+    } else {
     const bool defer3 = !QUAD && kBurstStores<BITS, CHF, true> && c == 1 && (reinterpret_cast<uintptr_t>(body) & 63u) == 3u;
     const uint32_t deferred = write_block_header(F, out + block_off + (uint64_t)c * kBlockHeaderBytesPerCh, writer, defer3);
     if constexpr (QUAD) L = to_quad(F, tap); else L = F;
@@ -1375,8 +1666,10 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
     (void)run_block<BITS, CHF, MS, QUAD, true>(L, src, first, n, ch, c, writer, body, lds, last_qd, defer3, deferred);
     if constexpr (QUAD) F = from_quad<kEncTM>(L); else F = L;
     }
+    }
     AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   }
+  if constexpr (RING) ring.finish(); /* the stream's last, incomplete sector */
 
   if (a.state_out && writer) {
     LaneStateRecord r;

@@ -235,6 +235,37 @@ bool pick_quad(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels
 }
 
 /* lds_pad: dynamic LDS the kernel never touches - it only lowers the number of workgroups a CU holds (see dense_encode_lds_pad) */
+/* the dense encoders whose output goes through the rows' byte rings (aad_encode.hip.h ByteRing): mono / stereo, 4- and 2-bit */
+template <int BITS, bool TRIALS>
+bool launch_encode_ring(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream, unsigned lds_pad)
+{
+  if constexpr (BITS == 4 || BITS == 2) {
+    if (a.channels == 1)
+      hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
+    else if (a.channels == 2 && a.mid_side)
+      hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
+    else if (a.channels == 2)
+      hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
+    else
+      return false;
+    return true;
+  }
+  return false;
+}
+
+/* Which dense encoders append to the byte ring.  Policy (same-box A/B on the saturated batches, profiles/r03_encoder_byte_ring.txt):
+ * mono 4- / 2-bit and stereo 4-bit - yes (their writes fall from 1.3-2.1x to 1.00-1.06x of the code bytes and the kernels get 0-7 %
+ * faster); stereo 2-bit - no: it is VALU-saturated (95 % active), wrote only 1.18x in total before, and the ring's extra ~1 VALU
+ * instruction per sample costs it 4-7 % of its time for 1.01x.  AAD_HIP_ENCODE_RING (read at every launch: the tests flip it)
+ * = 0: never (A/B measurements), = 2: every geometry that can. */
+bool encode_ring_wanted(uint32_t bits, uint32_t channels)
+{
+  const char *e = getenv("AAD_HIP_ENCODE_RING");
+  if (e != nullptr && e[0] == '0') return false;
+  if (e != nullptr && e[0] == '2') return true;
+  return !(bits == 2 && channels == 2);
+}
+
 template <int BITS, bool QUAD, bool TRIALS, bool DUAL>
 void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream, unsigned lds_pad = 0)
 {
@@ -303,9 +334,13 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
   } else {
     if (quad) launch_encode_mapped<BITS, true, false, false>(a, grid, block, stream);
     else {
-      const unsigned static_lds = a.channels == 1 ? (unsigned)aad::kLdsBytesEncoder<BITS, 1, false>
-                                                  : (a.channels == 2 ? (unsigned)aad::kLdsBytesEncoder<BITS, 2, false> : (unsigned)aad::kLdsBytesEncoder<BITS, 0, false>);
-      launch_encode_mapped<BITS, false, false, false>(a, grid, block, stream, wg == 256u ? dense_encode_lds_pad(BITS, lanes, static_lds) : 0u);
+      const bool ring = a.ring_ok && a.channels <= 2 && (BITS == 4 || BITS == 2) && encode_ring_wanted(BITS, a.channels);
+      const unsigned static_lds = ring ? (unsigned)(a.channels == 1 ? aad::kLdsBytesEncoderRing<BITS, 1, false, true> : aad::kLdsBytesEncoderRing<BITS, 2, false, true>)
+                                  : (a.channels == 1 ? (unsigned)aad::kLdsBytesEncoder<BITS, 1, false>
+                                                     : (a.channels == 2 ? (unsigned)aad::kLdsBytesEncoder<BITS, 2, false> : (unsigned)aad::kLdsBytesEncoder<BITS, 0, false>));
+      const unsigned pad = wg == 256u ? dense_encode_lds_pad(BITS, lanes, static_lds) : 0u;
+      if (!(ring && launch_encode_ring<BITS, false>(a, grid, block, stream, pad)))
+        launch_encode_mapped<BITS, false, false, false>(a, grid, block, stream, pad);
     }
   }
 }
@@ -459,6 +494,13 @@ AADApiResult encode_plan_init(const struct AADEncodeParameter *parameter, uint32
   args->trials = parameter->num_encode_trials;
   args->lead_frames = lead_frames;
   args->uni = detect_uniform(num_streams, streams);
+  /* the rows' byte rings store whole 64-byte sectors of an image at their own addresses: images on 64-byte boundaries */
+  args->ring_ok = 1;
+  for (uint32_t i = 0; i < num_streams; i++)
+    if (streams[i].data_offset % 64u != 0) {
+      args->ring_ok = 0;
+      break;
+    }
   h.num_samples = 0;
   AADFormat_PutHeader(&h, args->header_template);
   args->bits = h.bits_per_sample;
@@ -538,6 +580,7 @@ AADApiResult run_encode(AADHipContext *ctx, const aad::EncodeArgs &args)
   aad::EncodeArgs a = args;
   a.trial_scratch = nullptr;
   a.trial_slot_bytes = 0;
+  if ((reinterpret_cast<uintptr_t>(a.data) & 63u) != 0) a.ring_ok = 0;
   if (a.trials != 0 && a.channels <= 2 && ctx->trial_lanes != AAD_HIP_TRIAL_LANES_SINGLE &&
       pick_quad(ctx, (uint64_t)a.num_streams * a.channels, a.channels, a.bits)) {
     const uint64_t want = (uint64_t)a.num_streams * 3u * trial_slot_bytes(a);
