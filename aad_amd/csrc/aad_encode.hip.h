@@ -704,18 +704,19 @@ struct ByteRing {
   /* n_bytes (8 or 4, the same on both lanes of a pair) of this lane in memory order in d0 (and d1): behind the bytes of the
    * lanes before it.  sel: ring_selectors of (pos + c * n_bytes) & 3 - the caller keeps them per block. */
   template <int N>
-  __device__ __forceinline__ void append(uint32_t d0, uint32_t d1, const RingSelectors &sel)
+  __device__ __forceinline__ void append(uint32_t d0, uint32_t d1, const RingSelectors &sel, uint32_t d2 = 0)
   {
-    static_assert(N == 8 || N == 4, "whole dwords");
+    static_assert(N == 12 || N == 8 || N == 4, "whole dwords");
     /* this lane's carry-in: mono - its own carry; stereo - lane 0 takes lane 1's carry of the previous chunk, lane 1 takes
      * lane 0's of this one (same byte phase on both lanes: their pieces are whole dwords long) */
-    const uint32_t out = N == 8 ? perm(0u, d1, sel.keep) : perm(0u, d0, sel.keep);
+    const uint32_t out = perm(0u, N == 12 ? d2 : (N == 8 ? d1 : d0), sel.keep);
     uint32_t in = carry;
     if (CHF == 2) in = pair_swap<false>(c ? carry : out, c);
     const uint32_t p = pos + c * N;
     const uint32_t m0 = perm(d0, in, sel.take);
     *reinterpret_cast<uint32_t *>(at(p & ~3u)) = m0;
-    if (N == 8) *reinterpret_cast<uint32_t *>(at((p & ~3u) + 4u)) = perm(d1, d0, sel.shift);
+    if (N >= 8) *reinterpret_cast<uint32_t *>(at((p & ~3u) + 4u)) = perm(d1, d0, sel.shift);
+    if (N == 12) *reinterpret_cast<uint32_t *>(at((p & ~3u) + 8u)) = perm(d2, d1, sel.shift);
     carry = out;
     advance(N * CHF);
   }
@@ -771,7 +772,7 @@ template <int BITS, int CHF, bool QUAD>
 constexpr int kLdsBytesEncoder = kStagedCodes<BITS, CHF, QUAD> ? kLdsCodeStageOff + 4 * 8 * 64 * (BITS == 2 ? 4 : 8) : kLdsBytesQuadEnc;
 /* the instantiations that move their output through ByteRing: dense, mono / stereo, 4- and 2-bit codes (pieces of whole dwords) */
 template <int BITS, int CHF, bool QUAD>
-constexpr bool kRingable = !QUAD && (CHF == 1 || CHF == 2) && (BITS == 4 || BITS == 2);
+constexpr bool kRingable = !QUAD && (CHF == 1 || CHF == 2);
 template <int CHF>
 constexpr int kLdsRingBytes = 4 * (64 / (CHF ? CHF : 1)) * 144; /* four waves of rows */
 template <int BITS, int CHF, bool QUAD, bool RING>
@@ -800,6 +801,24 @@ __device__ __forceinline__ void chunk_bytes(const uint32_t *w, uint32_t c, uint3
   }
 }
 
+/* 3-bit codes: four units (24 bits each, the low three bytes of a code word) in memory order - twelve bytes, the whole dwords a
+ * ring append wants.  Mono: the units of two chunks; stereo: the L R L R units of one chunk of the pair. */
+__device__ __forceinline__ void units12(uint32_t u0, uint32_t u1, uint32_t u2, uint32_t u3, uint32_t &d0, uint32_t &d1, uint32_t &d2)
+{
+  d0 = perm(u1, u0, 0x06000102);
+  d1 = perm(u2, u1, 0x05060001);
+  d2 = perm(u3, u2, 0x04050600);
+}
+/* stereo 3-bit, two chunks of the pair (this lane's code words wa of chunk k, wb of chunk k + 1): lane 0 appends chunk k's twelve
+ * bytes, lane 1 chunk k + 1's - each gets the other channel's units of ITS chunk */
+__device__ __forceinline__ void pair_units12(const uint32_t *wa, const uint32_t *wb, uint32_t c, uint32_t &d0, uint32_t &d1, uint32_t &d2)
+{
+  const uint32_t r0 = pair_swap<false>(c ? wa[0] : wb[0], c), r1 = pair_swap<false>(c ? wa[1] : wb[1], c);
+  const uint32_t l0 = c ? r0 : wa[0], l1 = c ? r1 : wa[1]; /* channel 0's units of this lane's chunk */
+  const uint32_t q0 = c ? wb[0] : r0, q1 = c ? wb[1] : r1; /* channel 1's */
+  units12(l0, q0, l1, q1, d0, d1, d2);
+}
+
 /* the dense stereo 4-bit encode pass stores its codes four chunks at a time (run_block) */
 template <int BITS, int CHF, bool EMIT>
 constexpr bool kBurstStores = EMIT && CHF == 2 && BITS == 4;
@@ -825,8 +844,8 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
                                              ByteRing<(CHF ? CHF : 1)> *ring = nullptr)
 {
   constexpr bool EMIT = PASS != kPassRmse;
-  static_assert(!RING || (EMIT && kRingable<BITS, CHF, QUAD>), "the byte ring serves the dense 4- / 2-bit encode passes");
-  constexpr int kPiece = BITS == 4 ? 8 : 4; /* RING: bytes of a chunk per lane */
+  static_assert(!RING || (EMIT && kRingable<BITS, CHF, QUAD>), "the byte ring serves the dense mono / stereo encode passes");
+  constexpr int kPiece = BITS == 4 ? 8 : (BITS == 3 ? 12 : 4); /* RING: bytes per lane and append (3-bit: of two chunks) */
   RingSelectors ring_sel = {0, 0, 0};
   if constexpr (RING) ring_sel = ring_selectors((ring->pos + c * kPiece) & 3u);
   static_assert(PASS != kPassBoth || QUAD, "measurement and encode in one pass: quad mapping only");
@@ -1139,6 +1158,10 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
             for (int j = 0; j < 16; j++) cur.d[j] = np.d[j];
             if constexpr (RING && BITS == 2) { /* the pair's two dwords in one append: one carry, one boundary test */
               ring->template append<8>(perm(0, wa[0], 0x00010203), perm(0, wb[0], 0x00010203), ring_sel);
+            } else if constexpr (RING && BITS == 3) { /* two chunks are twelve bytes */
+              uint32_t d0, d1, d2;
+              units12(wa[0], wa[1], wb[0], wb[1], d0, d1, d2);
+              ring->template append<12>(d0, d1, ring_sel, d2);
             } else if constexpr (RING) {
               uint32_t d0, d1;
               chunk_bytes<BITS, CHF>(wa, c, d0, d1);
@@ -1155,6 +1178,26 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
           xp += (uint64_t)pairs * 2 * kChunk; /* the chunk behind the last pair */
           if (k0 < full) next.load(xp, ch, c);
           next.touch();
+        }
+      }
+      if constexpr (RING && CHF == 2 && BITS == 3) {
+        /* stereo 3-bit through the ring: two chunks per append, twelve bytes per lane (pair_units12) */
+        for (; k0 + 2 <= full; k0 += 2) {
+          uint32_t w2[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            int32_t x[kN];
+#pragma unroll
+            for (int j = 0; j < kN; j++) x[j] = PK ? (int32_t)next.pair(j, pair_sel) : next.get(j, c);
+            if (k0 + h + 1 < full) xp += (uint64_t)kChunk * ch;
+            next.load(xp, ch, c);
+            w2[h][0] = w2[h][1] = 0;
+            encode_chunk16<BITS, EMIT, PK>(L, x, lds, w2[h], last_qd, sq);
+            next.touch();
+          }
+          uint32_t d0, d1, d2;
+          pair_units12(w2[0], w2[1], c, d0, d1, d2);
+          ring->template append<12>(d0, d1, ring_sel, d2);
         }
       }
       if constexpr (RING && CHF == 2 && BITS == 2) {
@@ -1190,7 +1233,16 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         uint32_t w[2] = {0, 0};
         encode_chunk16<BITS, EMIT, PK>(L, x, lds, w, last_qd, sq);
         next.touch();
-        if constexpr (RING) {
+        if constexpr (RING && BITS == 3) {
+          /* the one chunk two-chunk appends leave over (the last of its block): six bytes per lane, byte by byte */
+          ring->carry_to_ring();
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) ring->put_byte(ring->pos + (u * (CHF ? CHF : 1) + c) * 3u + q, w[u] >> (8 * (2 - q)));
+          ring->advance(6u * (CHF ? CHF : 1));
+          ring->carry_from_ring();
+        } else if constexpr (RING) {
           uint32_t d0, d1;
           chunk_bytes<BITS, CHF>(w, c, d0, d1);
           ring->template append<kPiece>(d0, d1, ring_sel);
@@ -1556,7 +1608,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 {
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
-  static_assert(!RING || kRingable<BITS, CHF, QUAD>, "the byte ring: dense mono / stereo encoders, 4- and 2-bit codes");
+  static_assert(!RING || kRingable<BITS, CHF, QUAD>, "the byte ring: dense mono / stereo encoders");
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytesEncoderRing<BITS, CHF, QUAD, RING>]; /* dense and quad encoders share the wide table; dense: + code staging or the rows' byte rings */
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, true, kWideStepShift, true>(lds);

@@ -235,35 +235,32 @@ bool pick_quad(const AADHipContext *ctx, uint64_t recurrences, uint32_t channels
 }
 
 /* lds_pad: dynamic LDS the kernel never touches - it only lowers the number of workgroups a CU holds (see dense_encode_lds_pad) */
-/* the dense encoders whose output goes through the rows' byte rings (aad_encode.hip.h ByteRing): mono / stereo, 4- and 2-bit */
+/* the dense encoders whose output goes through the rows' byte rings (aad_encode.hip.h ByteRing): mono / stereo */
 template <int BITS, bool TRIALS>
 bool launch_encode_ring(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream, unsigned lds_pad)
 {
-  if constexpr (BITS == 4 || BITS == 2) {
-    if (a.channels == 1)
-      hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
-    else if (a.channels == 2 && a.mid_side)
-      hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
-    else if (a.channels == 2)
-      hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
-    else
-      return false;
-    return true;
-  }
-  return false;
+  if (a.channels == 1)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
+  else if (a.channels == 2 && a.mid_side)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
+  else if (a.channels == 2)
+    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
+  else
+    return false;
+  return true;
 }
 
 /* Which dense encoders append to the byte ring.  Policy (same-box A/B on the saturated batches, profiles/r03_encoder_byte_ring.txt):
- * mono 4- / 2-bit and stereo 4-bit - yes (their writes fall from 1.3-2.1x to 1.00-1.06x of the code bytes and the kernels get 0-7 %
- * faster); stereo 2-bit - no: it is VALU-saturated (95 % active), wrote only 1.18x in total before, and the ring's extra ~1 VALU
- * instruction per sample costs it 4-7 % of its time for 1.01x.  AAD_HIP_ENCODE_RING (read at every launch: the tests flip it)
- * = 0: never (A/B measurements), = 2: every geometry that can. */
+ * every mono encoder and the stereo 4-bit one - their writes fall from 1.3-2.1x to 1.00-1.06x of the code bytes and the kernels
+ * get 3-8 % faster; stereo 3- and 2-bit - no: they are VALU-saturated (95 % active), wrote only 1.18x in total before, and the
+ * ring's extra ~1 VALU instruction per sample costs them 3-7 % of their time.  AAD_HIP_ENCODE_RING (read at every launch: the
+ * tests flip it) = 0: never (A/B measurements), = 2: every geometry that can. */
 bool encode_ring_wanted(uint32_t bits, uint32_t channels)
 {
   const char *e = getenv("AAD_HIP_ENCODE_RING");
   if (e != nullptr && e[0] == '0') return false;
   if (e != nullptr && e[0] == '2') return true;
-  return !(bits == 2 && channels == 2);
+  return channels == 1 || bits == 4;
 }
 
 template <int BITS, bool QUAD, bool TRIALS, bool DUAL>
@@ -334,7 +331,7 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
   } else {
     if (quad) launch_encode_mapped<BITS, true, false, false>(a, grid, block, stream);
     else {
-      const bool ring = a.ring_ok && a.channels <= 2 && (BITS == 4 || BITS == 2) && encode_ring_wanted(BITS, a.channels);
+      const bool ring = a.ring_ok && a.channels <= 2 && encode_ring_wanted(BITS, a.channels);
       const unsigned static_lds = ring ? (unsigned)(a.channels == 1 ? aad::kLdsBytesEncoderRing<BITS, 1, false, true> : aad::kLdsBytesEncoderRing<BITS, 2, false, true>)
                                   : (a.channels == 1 ? (unsigned)aad::kLdsBytesEncoder<BITS, 1, false>
                                                      : (a.channels == 2 ? (unsigned)aad::kLdsBytesEncoder<BITS, 2, false> : (unsigned)aad::kLdsBytesEncoder<BITS, 0, false>));

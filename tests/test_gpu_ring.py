@@ -25,7 +25,7 @@ def engine():
     e.close()
 
 
-@pytest.mark.parametrize("bits", [4, 2])
+@pytest.mark.parametrize("bits", [4, 3, 2])
 @pytest.mark.parametrize("channels", [1, 2])
 @pytest.mark.parametrize("uniform", [True, False])
 def test_ring_encoder_matches_oracle(engine, bits, channels, uniform, monkeypatch):
@@ -86,13 +86,13 @@ def test_ring_encoder_matches_oracle(engine, bits, channels, uniform, monkeypatc
         engine.set_mapping("auto")
 
 
-@pytest.mark.parametrize("bits,channels", [(4, 2), (4, 1), (2, 2), (2, 1)])
+@pytest.mark.parametrize("bits,channels", [(4, 2), (4, 1), (3, 2), (3, 1), (2, 2), (2, 1)])
 def test_ring_encoder_chip_filling_batch(engine, bits, channels, monkeypatch):
     """a batch big enough for "auto" to take the dense encoders (workgroups of four waves: four waves of rows share the ring
     area), two blocks per stream - against the oracle on a sample of streams, and every repetition of the tile against the first"""
     import torch
     monkeypatch.setenv("AAD_HIP_ENCODE_RING", "2")
-    spb = {4: 1984, 2: 3960}[bits] // channels
+    spb = {4: 1984, 3: 2632, 2: 3960}[bits] // channels
     streams = 70000 // channels
     param = make_parameter(channels, bits, 1024, 48000, False, 0)
     tile = torch.from_numpy(synth_pcm(300, 2 * spb, channels, seed=77)).cuda()

@@ -27,7 +27,8 @@ def main():
     param = make_parameter(args.channels, args.bits, 1024, 48000, False, 0)
     engine = Engine(0)
     torch.cuda.set_stream(engine.stream)
-    spb = {4: 1984, 3: 2632, 2: 3960}[args.bits] // args.channels if args.channels <= 2 else None
+    # samples per channel of one 1024-byte block (mono / stereo: the reference's geometry; 8 channels: BASELINE config 4's segments)
+    spb = {4: 1984, 3: 2632, 2: 3960}[args.bits] // args.channels if args.channels <= 2 else {(8, 3): 292, (8, 2): 444}[(args.channels, args.bits)]
     samples = spb * args.blocks
     base = torch.from_numpy(synth_pcm(1000, samples, args.channels, seed=1234)).cuda()
     pcm = base.repeat((-(-args.streams // 1000), 1, 1))[:args.streams].contiguous()
