@@ -205,6 +205,7 @@ struct DecodeArgs {
   uint32_t bits;
   uint32_t stream_stores; /* dense stereo kernel: every chunk store of every block is a whole 64-byte granule (host-checked): launch the NT instantiation */
   uint32_t pcm_aligned16; /* every stream's PCM starts on a 16-byte boundary relative to `pcm` (host-checked): what the sector-tiled kernel needs */
+  uint32_t code_phase_uniform; /* every block of every stream starts at the same offset inside a granule (64 bytes mono, 128 stereo) relative to `data` (host-checked; 2: if no stream has a second block): 3-bit rows on the sector-tiled kernel */
   UniformLayout uni;
 };
 

@@ -9,12 +9,14 @@ namespace aad {
 bool decode_tiled_applicable(const DecodeArgs &a)
 {
   if (a.channels < 1 || a.channels > 2) return false;
-  if (a.bits != 4 && a.bits != 2) return false;
+  if (a.bits < 2 || a.bits > 4) return false;
   if (!a.pcm_aligned16) return false;
   /* every block of a stream starts on a piece boundary: the block length in PCM bytes is a multiple of 16 (mono 2-bit
    * blocks of 1024 bytes hold 4028 samples = 8056 bytes: not) - or no stream has a second block */
   if (((uint64_t)a.samples_per_block * a.channels * 2u) % 16u != 0 && a.total_blocks > a.num_streams) return false;
   if ((reinterpret_cast<uintptr_t>(a.pcm) & 15u) != 0) return false;
+  /* 3-bit rows: the code bytes of every block at the same offset inside their granule (aad_decode_tiled.hip.h "3-bit rows") */
+  if (a.bits == 3 && !(a.code_phase_uniform == 1 || (a.code_phase_uniform == 2 && a.total_blocks <= a.num_streams))) return false;
   return true;
 }
 
@@ -33,8 +35,10 @@ bool launch_decode_tiled(const DecodeArgs &a, hipStream_t stream)
 {
   if (!decode_tiled_applicable(a)) return false;
   const uint64_t lanes = a.total_blocks * a.channels;
-  const dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
+  const unsigned wg = 64u * DecodeTile<4, 1>::kWaves;
+  const dim3 grid((unsigned)((lanes + wg - 1) / wg)), block(wg);
   if (a.bits == 4) launch_bits<4>(a, grid, block, stream);
+  else if (a.bits == 3) launch_bits<3>(a, grid, block, stream);
   else launch_bits<2>(a, grid, block, stream);
   return true;
 }

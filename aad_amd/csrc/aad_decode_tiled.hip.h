@@ -26,8 +26,8 @@
  * (stereo) bytes per row = 17 KB per wave, so a CU holds 8 waves (two per SIMD) - enough, because what
  * is left to wait for is LDS, and the chunk body was software-pipelined for a lone wave.
  *
- * Scope: 4- and 2-bit codes (a 3-bit chunk is 6 bytes, which divides no granule: those streams keep the
- * per-lane kernel), mono / stereo, every block's PCM 16-byte aligned (host-checked: uniform batches are).
+ * Scope: mono / stereo, every block's PCM 16-byte aligned (host-checked: uniform batches are); 3-bit codes (a chunk is 6 / 12
+ * bytes, which divide no granule) only in batches whose code bytes share their phase - see "3-bit rows" below.
  * Blocks shorter than a chunk, truncated images and the last samples of a block take the same per-lane
  * tail as decode_blocks_kernel; both kernels produce identical bytes (tests run them side by side).
  */
@@ -40,7 +40,9 @@ namespace aad {
 
 template <int BITS, int CHF>
 struct DecodeTile {
-  static_assert((BITS == 4 || BITS == 2) && (CHF == 1 || CHF == 2), "4- / 2-bit codes, mono / stereo");
+  static_assert((BITS == 4 || BITS == 3 || BITS == 2) && (CHF == 1 || CHF == 2), "mono / stereo");
+  static constexpr bool k3 = BITS == 3;                        /* 3-bit codes: see "3-bit rows" below */
+  static constexpr int kWaves = 4;                             /* waves per workgroup */
   static constexpr int kRows = 64 / CHF;                       /* rows (blocks) per wave */
   static constexpr int kG = CHF == 1 ? 64 : 128;               /* granule bytes, both directions */
   static constexpr int kGLog2 = CHF == 1 ? 6 : 7;
@@ -49,12 +51,14 @@ struct DecodeTile {
   /* the output ring carries 16 bytes of padding: rows a multiple of 128 bytes apart put the same piece of every row on
    * the same banks (an eight-way conflict on every ds_write_b128 of packed PCM) */
   static constexpr int kInPitch = kRing + kMirror, kOutPitch = kRing + 16;
-  static constexpr int kCb = Pack<BITS>::kChunkBytes * CHF;    /* code bytes of a row per chunk: 8 / 16 (4-bit), 4 / 8 (2-bit) */
-  static constexpr int kInPeriod = kG / kCb;                   /* chunks per input granule: 8 (4-bit), 16 (2-bit) */
+  static constexpr int kCb = Pack<BITS>::kChunkBytes * CHF;    /* code bytes of a row per chunk: 8 / 16 (4-bit), 6 / 12 (3-bit), 4 / 8 (2-bit) */
+  static constexpr int kInPeriod = k3 ? 0 : kG / kCb;          /* chunks per input granule: 8 (4-bit), 16 (2-bit); 3-bit: 10 2/3 */
   static constexpr int kPcmBytes = 2 * kChunk * CHF;           /* PCM bytes of a row per chunk: 32 / 64 */
   static_assert(kG / kPcmBytes == 2, "an output granule is two chunks");
-  static constexpr int kLead = 12;                             /* decoded samples of the lead chunk (+ 4 verbatim) */
+  static constexpr int kLead = k3 ? 0 : 12;                    /* decoded samples of the lead chunk (+ 4 verbatim); 3-bit: none */
   static constexpr int kLeadBytes = kLead * BITS / 8 * CHF;
+  static constexpr int kShift = k3 ? 2 * kTaps * CHF : 0;      /* 3-bit: chunk j's PCM starts kShift + j * kPcmBytes into the block */
+  static constexpr int kRaw = (kCb + 3) / 4 + 1;               /* aligned dwords that hold a chunk's code bytes at any byte phase */
   static constexpr int kLanesPerRow = kG / 16;                 /* lanes that cover one granule: 4 / 8 */
   static constexpr int kRowsPerInst = 64 / kLanesPerRow;       /* 16 / 8 */
   static constexpr int kInst = kRows / kRowsPerInst;           /* wave-level accesses per granule of every row: 4 */
@@ -76,6 +80,18 @@ static_assert(sizeof(RowMeta) == 32, "RowMeta is one 32-byte LDS record");
 
 constexpr int kLdsTileOff = (kLdsBytesDenseDec + 15) & ~15;
 
+/*
+ * 3-bit rows.  A 3-bit unit is eight samples in three bytes, so (a) no lead chunk of twelve samples exists: the four verbatim
+ * samples go into the output ring by themselves and chunk j's PCM sits 8 (mono) / 16 (stereo) bytes further on - mono chunks
+ * are written as 8 + 16 + 8 bytes (three aligned LDS writes), a row's last piece may be half a piece (stored as 8 bytes), and an
+ * output granule is complete one chunk later than on 4- / 2-bit rows; (b) a chunk is 6 / 12 code bytes, which divide no granule:
+ * rows of different byte phase would be up to three granules apart at the same chunk, and a third ring slot does not fit eight
+ * waves per CU (measured with three slots and six waves: VALU-active 63 % instead of 80 %, no faster than the per-lane kernel).
+ * So 3-bit rows take this kernel only when EVERY row's code bytes sit at the same offset U inside their granule (host-checked,
+ * DecodeArgs::code_phase_uniform: image pitch and block size multiples of 128 bytes - uniform batches are built that way); the
+ * next granule then goes in when chunk j's aligned dwords first reach it: need(j) = (((U + kCb * j) & ~3) + 4 * kRaw - 1) >> kGLog2;
+ * (c) a mono chunk's byte phase alternates (6 = 2 mod 4).
+ */
 /*
  * A chunk in two strands.  What a sample needs from the tables - its code's record and the step size at its step index -
  * depends on the CODES only (idx' = clamp(idx + delta[code]) never sees a sample), so all sixteen lookups of a chunk are
@@ -99,7 +115,7 @@ __device__ __forceinline__ void walk_chunk(int32_t &idxb, const uint32_t *w, con
     constexpr int j = decltype(jc)::value;
     constexpr int sh = 3, pos = Pack<BITS>::pos(j % cpw);
     const uint32_t word = w[j / cpw];
-    const uint32_t addr = (pos >= sh ? word >> (pos >= sh ? pos - sh : 0) : word << (sh - pos)) & (((1u << BITS) - 1u) << sh);
+    const uint32_t addr = (pos >= sh ? word >> (pos >= sh ? pos - sh : 0) : word << (pos >= sh ? 0 : sh - pos)) & (((1u << BITS) - 1u) << sh);
     W.rec[j] = *reinterpret_cast<const u32x2 *>(lds + kLdsDenseCode8Off + addr);
   });
   static_for<0, kChunk>([&](auto jc) {
@@ -123,12 +139,13 @@ __device__ __forceinline__ void run_chunk(Lane &L, const ChunkWalk &W, int32_t &
 }
 
 template <int BITS, int CHF, bool MS>
-__global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
+__global__ void __launch_bounds__((64 * DecodeTile<BITS, CHF>::kWaves), 2) decode_tiled_kernel(DecodeArgs a)
 {
   using T = DecodeTile<BITS, CHF>;
+  constexpr bool k3 = T::k3;
   constexpr uint32_t ch = CHF;
   constexpr uint32_t kRingMask = T::kRing - 1;
-  __shared__ __attribute__((aligned(16))) char lds[kLdsTileOff + 4 * T::kWaveBytes];
+  __shared__ __attribute__((aligned(16))) char lds[kLdsTileOff + T::kWaves * T::kWaveBytes];
   stage_tables<BITS, false>(lds);
   stage_dense_decode_tables<BITS>(lds);
 
@@ -171,7 +188,8 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
 
   constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
   const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
-  const bool lead = coded >= (uint32_t)T::kLead && avail >= body + T::kLeadBytes;
+  /* lead: the row's first samples go through the output ring - 4- / 2-bit: the lead chunk (4 verbatim + 12 decoded); 3-bit: the 4 verbatim */
+  const bool lead = k3 ? (n >= (uint32_t)kTaps) : (coded >= (uint32_t)T::kLead && avail >= body + T::kLeadBytes);
   uint32_t full = 0; /* whole 16-sample chunks behind the lead chunk whose code bytes are all there */
   if (lead) {
     full = (coded - T::kLead) / kChunk;
@@ -195,7 +213,7 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
     if (m.g_max < m.g_min) m.g_max = m.g_min;
     m.out_base = out_base;
     m.lo = theta;
-    m.hi = theta + (lead ? (1u + full) * T::kPcmBytes : 0u);
+    m.hi = theta + (lead ? (k3 ? T::kShift + full * T::kPcmBytes : (1u + full) * T::kPcmBytes) : 0u);
     *reinterpret_cast<RowMeta *>(tile + T::kMetaOff + my_row * T::kMetaBytes) = m;
   }
   /* trip count of the wave: the longest row's */
@@ -250,8 +268,14 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
   auto write_granule = [&](uint32_t t, const u32x4 (&r)[T::kInst]) { /* ... to memory, the pieces that belong to their row */
     const uint32_t at = t * T::kG + 16u * piece;
 #pragma unroll
-    for (int i = 0; i < T::kInst; i++)
-      if (at >= mv_lo[i] && at < mv_hi[i]) store_through(mv_out[i] + (uint64_t)t * T::kG, r[i]);
+    for (int i = 0; i < T::kInst; i++) {
+      if (k3 && CHF == 1) { /* a mono 3-bit row ends 8 bytes into a piece */
+        if (at >= mv_lo[i] && at + 16u <= mv_hi[i]) store_through(mv_out[i] + (uint64_t)t * T::kG, r[i]);
+        else if (at >= mv_lo[i] && at < mv_hi[i]) *reinterpret_cast<u32x2 *>(mv_out[i] + (uint64_t)t * T::kG) = u32x2{r[i].x, r[i].y};
+      } else if (at >= mv_lo[i] && at < mv_hi[i]) {
+        store_through(mv_out[i] + (uint64_t)t * T::kG, r[i]);
+      }
+    }
   };
 
   /* ---- prologue: granules -1 and 0 (block header, lead chunk, first codes) and granule 1 */
@@ -298,37 +322,63 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
    * chunk's big-endian code words from them.  The byte phase pos & 3 is absorbed by the selector of a v_perm_b32
    * (mono) or by v_alignbyte_b32 (stereo: the pair's L/R-interleaved bytes are realigned, then this channel's
    * picked); it is the same for every chunk of a block (a chunk is 4 .. 16 bytes). */
-  constexpr int kRaw = T::kCb / 4 + 1;
+  constexpr int kRaw = T::kRaw;
   auto fetch_raw = [&](int32_t pos, uint32_t (&raw)[kRaw]) {
     const char *at = in_ring + ((uint32_t)pos & (kRingMask & ~3u));
 #pragma unroll
     for (int k = 0; k < kRaw; k++) raw[k] = *reinterpret_cast<const uint32_t *>(at + 4 * k);
   };
   auto unpack = [&](const uint32_t (&raw)[kRaw], uint32_t ph, uint32_t *w) {
-    if (CHF == 1) {
+    if constexpr (k3) {
+      /* the chunk's bytes from phase 0: E0 .. E7 (mono: six of them) or E0 .. E11 (the pair's L R L R units) */
+      uint32_t e[kRaw - 1];
+#pragma unroll
+      for (int k = 0; k < kRaw - 1; k++) e[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], ph);
+      if constexpr (CHF == 1) {
+        w[0] = perm(0u, e[0], 0x0c000102);    /* E0 E1 E2 */
+        w[1] = perm(e[1], e[0], 0x0c030405);  /* E3 E4 E5 */
+      } else {
+        w[0] = perm(e[1], e[0], c ? 0x0c030405u : 0x0c000102u); /* E3 E4 E5 : E0 E1 E2 */
+        w[1] = perm(e[2], e[1], c ? 0x0c050607u : 0x0c020304u); /* E9 E10 E11 : E6 E7 E8 */
+      }
+    } else if constexpr (CHF == 1) {
       const uint32_t sel = 0x00010203u + 0x01010101u * ph; /* bytes ph .. ph + 3 of a dword pair, most significant first */
       w[0] = perm(raw[1], raw[0], sel);
-      if (BITS == 4) w[1] = perm(raw[2], raw[1], sel);
+      if constexpr (BITS == 4) w[1] = perm(raw[2], raw[1], sel);
     } else {
       uint32_t e[kRaw - 1];
 #pragma unroll
       for (int k = 0; k < kRaw - 1; k++) e[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], ph);
       const uint32_t pick = 0x00020406u + c * 0x01010101u;
       w[0] = perm(e[1], e[0], pick);
-      if (BITS == 4) w[1] = perm(e[3], e[2], pick);
+      if constexpr (BITS == 4) w[1] = perm(e[3], e[2], pick);
     }
   };
   auto put_pcm = [&](uint32_t x, const ChunkPcm &o) { /* x: the chunk's first PCM byte, relative to the block's */
+    if constexpr (k3 && CHF == 1) { /* x = 8 mod 16: 8 + 16 + 8 bytes, each piece aligned to its size (a piece never wraps) */
+      *reinterpret_cast<u32x2 *>(out_ring + ((theta + x) & kRingMask)) = u32x2{o.v[0].x, o.v[0].y};
+      *reinterpret_cast<u32x4 *>(out_ring + ((theta + x + 8u) & kRingMask)) = u32x4{o.v[0].z, o.v[0].w, o.v[1].x, o.v[1].y};
+      *reinterpret_cast<u32x2 *>(out_ring + ((theta + x + 24u) & kRingMask)) = u32x2{o.v[1].z, o.v[1].w};
+    } else {
 #pragma unroll
-    for (int h = 0; h < 2; h++)
-      *reinterpret_cast<u32x4 *>(out_ring + ((theta + x + (CHF == 1 ? 16u * h : 32u * h + 16u * c)) & kRingMask)) = o.v[h];
+      for (int h = 0; h < 2; h++)
+        *reinterpret_cast<u32x4 *>(out_ring + ((theta + x + (CHF == 1 ? 16u * h : 32u * h + 16u * c)) & kRingMask)) = o.v[h];
+    }
   };
 
   const int32_t s_pos = (int32_t)(code0 - in_base); /* first code byte behind the lead chunk, 0 <= s_pos < kG */
   uint32_t raw[kRaw];
   ChunkPcm pending; /* the packed PCM of the chunk just decoded: written to the ring after the next chunk's code bytes are asked for */
   pending.v[0] = pending.v[1] = u32x4{0, 0, 0, 0};
-  if (lead) {
+  if constexpr (k3) {
+    if (lead) { /* the verbatim frames: the rows' first kShift bytes of the output ring (theta + kShift <= kG: no wrap) */
+      int16_t *v = reinterpret_cast<int16_t *>(out_ring + theta) + c;
+      v[0] = (int16_t)y0;
+      v[ch] = (int16_t)y1;
+      v[2 * ch] = (int16_t)y2;
+      v[3 * ch] = (int16_t)y3;
+    }
+  } else if (lead) {
     uint32_t w[2] = {0, 0};
     fetch_raw(s_pos - T::kLeadBytes, raw);
     unpack(raw, (uint32_t)(s_pos - T::kLeadBytes) & 3u, w);
@@ -337,9 +387,10 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
     y[1] = y1;
     y[2] = y2;
     y[3] = y3;
-    decode_chunk16<BITS, T::kLead, true>(L, w, lds, y + kTaps, finish);
+    decode_chunk16<BITS, (k3 ? kChunk : T::kLead), true>(L, w, lds, y + kTaps, finish);
     pending = pack_chunk_pcm<CHF, false>(y, c);
-  } else {
+  }
+  if (!lead) {
     if (n > 0) dst[0] = (int16_t)y0;
     if (n > 1) dst[ch] = (int16_t)y1;
     if (n > 2) dst[2 * ch] = (int16_t)y2;
@@ -349,10 +400,15 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
   put_granule(1, gn); /* over granule -1: header and lead chunk have been read */
   load_granule(2, gn);
   wave_lds_fence();
+  /* byte phase of a chunk's code bytes: constant within a block, except mono 3-bit (6-byte chunks): ph, ph ^ 2, ph, ... */
   const uint32_t ph = (uint32_t)s_pos & 3u;
+  const uint32_t ph_odd = (k3 && CHF == 1) ? ph ^ 2u : ph;
   int32_t pos = s_pos;
+  auto next_pos = [&]() { pos += T::kCb; };
+  /* 3-bit: the offset of the code bytes inside their granule, the same for every row of the batch (see "3-bit rows") */
+  const uint32_t uphase = k3 ? (uint32_t)__builtin_amdgcn_readfirstlane(s_pos) : 0u;
   fetch_raw(pos, raw);
-  if (lead) put_pcm(0, pending);
+  if (!k3 && lead) put_pcm(0, pending);
   ChunkWalk wa, wb; /* the tables of the chunk in arithmetic and of the one behind it */
   int32_t idx_run = L.idxb; /* the step index runs a chunk ahead of the samples */
   if (0 < full) {
@@ -360,7 +416,7 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
     unpack(raw, ph, w);
     walk_chunk<BITS>(idx_run, w, lds, wa);
   }
-  pos += T::kCb;
+  next_pos();
   fetch_raw(pos, raw); /* chunk 1's code bytes */
   int32_t p = predict(L);
   wave_lds_fence();
@@ -371,20 +427,26 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
    *   odd j: output granule (j - 1) / 2 is complete in every row since chunk j - 1 and chunk j is about to write over it in
    *     some: its pieces are read now and stored behind the chunk's arithmetic;
    *   strand 1 of chunk j + 1, strand 2 of chunk j, ask for chunk j + 2's code bytes, write chunk j's PCM. */
-  uint32_t x = T::kPcmBytes;
+  /* 3-bit: x = kShift + j * kPcmBytes, granule t is complete in every row once chunk 2t + 1 is written and chunk 2t + 2 writes
+   *   over it in some: it leaves at even j >= 2; the input granule `period + 2` goes in as soon as the chunk whose bytes this
+   *   iteration fetches (j + 2) needs it (see "3-bit rows"). */
+  uint32_t x = k3 ? T::kShift : T::kPcmBytes;
   int32_t period = 0;
-  auto one = [&](uint32_t j, const ChunkWalk &cur, ChunkWalk &next) {
-    if ((j + 2) % T::kInPeriod == 0) {
+  auto one = [&](uint32_t j, const ChunkWalk &cur, ChunkWalk &next, uint32_t ph_next) {
+    const bool refill = k3 ? (int32_t)((((uphase + T::kCb * (j + 2)) & ~3u) + 4 * kRaw - 1) >> T::kGLog2) > period + 1
+                           : (j + 2) % (k3 ? 1 : T::kInPeriod) == 0;
+    if (refill) {
       put_granule(period + 2, gn);
       period++;
       load_granule(period + 2, gn);
     }
     u32x4 leaving[T::kInst];
-    const bool store_now = (j & 1u) != 0;
-    if (store_now) read_granule((j - 1) >> 1, leaving);
+    const bool store_now = k3 ? ((j & 1u) == 0 && j >= 2) : (j & 1u) != 0;
+    const uint32_t t_now = k3 ? (j - 2) >> 1 : (j - 1) >> 1;
+    if (store_now) read_granule(t_now, leaving);
     if (j + 1 < full) {
       uint32_t w[2] = {0, 0};
-      unpack(raw, ph, w);
+      unpack(raw, ph_next, w);
       walk_chunk<BITS>(idx_run, w, lds, next);
     }
     if (j < full) {
@@ -392,21 +454,22 @@ __global__ void __launch_bounds__(256, 2) decode_tiled_kernel(DecodeArgs a)
       run_chunk<BITS>(L, cur, p, y, finish);
       pending = pack_chunk_pcm<CHF, false>(y, c);
     }
-    if (store_now) write_granule((j - 1) >> 1, leaving);
+    if (store_now) write_granule(t_now, leaving);
     wave_lds_fence();
-    pos += T::kCb;
+    next_pos();
     fetch_raw(pos, raw);
     if (j < full) put_pcm(x, pending);
     x += T::kPcmBytes;
     wave_lds_fence();
   };
   for (uint32_t j = 0; j < full_max; j += 2) {
-    one(j, wa, wb);
-    if (j + 1 < full_max) one(j + 1, wb, wa);
+    one(j, wa, wb, ph_odd); /* unpacks chunk j + 1 */
+    if (j + 1 < full_max) one(j + 1, wb, wa, ph);
   }
   L.idxb = idx_run; /* the tail continues where the last walked chunk ended */
-  /* what the rows still hold: the granules the loop has not stored */
-  for (uint32_t t = full_max >> 1; t <= (full_max >> 1) + 1; t++) {
+  /* what the rows still hold: the (two) granules the loop has not stored */
+  const uint32_t t_first = k3 ? (full_max ? (full_max - 1) >> 1 : 0u) : full_max >> 1;
+  for (uint32_t t = t_first; t <= t_first + 1; t++) {
     u32x4 leaving[T::kInst];
     read_granule(t, leaving);
     write_granule(t, leaving);

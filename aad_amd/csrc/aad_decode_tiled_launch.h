@@ -10,7 +10,7 @@
 
 namespace aad {
 struct DecodeArgs;
-/* true when decode_tiled_kernel can decode this plan: mono / stereo, 4- or 2-bit codes, every block's PCM 16-byte
+/* true when decode_tiled_kernel can decode this plan: mono / stereo, 3-bit codes only at a batch-wide code phase (DecodeArgs::code_phase_uniform), every block's PCM 16-byte
  * aligned (DecodeArgs::pcm_aligned16 from the stream table, the base pointer checked here) */
 bool decode_tiled_applicable(const DecodeArgs &args);
 /* decode_tiled_kernel<bits, channels, mid_side> over ceil(recurrences / 256) workgroups of 256 threads.

@@ -400,9 +400,11 @@ enum class DecodeMapping { Dense, QuadFused, QuadSplit };
  * Measured against the per-lane kernel (with its own occupancy cap) on one-block streams, same box, tools/saturated_probe.py
  * (profiles/r03_tiled_decode_crossover.txt): mono 4-bit wins from 65 536 blocks on (one wave per SIMD: 0.156 vs 0.198 ms;
  * 0.43 vs 0.48 ms at 196 608; 1.10 vs 1.29 ms at 524 288), stereo 4-bit from ~393 216 recurrences (0.42 vs 0.45 ms; equal at
- * 262 144, the per-lane kernel ahead below); mono 2-bit like mono 4-bit (2.15 vs 2.52 ms at 524 288 blocks).  On STEREO 2-bit
- * streams the tiled kernel moves 1.02x the algorithmic bytes instead of 1.35x but takes 3-7 % longer (1.04-1.08 vs 1.01-1.02 ms):
- * "auto" keeps the per-lane kernel there, AAD_HIP_LANE_MAPPING_DENSE_TILED selects the tiled one at any size. */
+ * 262 144, the per-lane kernel ahead below); mono 2-bit like mono 4-bit (2.15 vs 2.52 ms at 524 288 blocks); mono 3-bit (where
+ * the batch's layout admits it: aad_decode_tiled.hip.h "3-bit rows") 1.41-1.43 vs 1.70 ms at 524 288 blocks.  On STEREO 2-bit
+ * streams the tiled kernel moves 1.02x the algorithmic bytes instead of 1.35x but takes 3-7 % longer (1.04-1.08 vs 1.01-1.02 ms),
+ * on stereo 3-bit streams both take 0.73 ms: "auto" keeps the per-lane kernel there, AAD_HIP_LANE_MAPPING_DENSE_TILED selects the
+ * tiled one at any size. */
 uint64_t tiled_decode_min(uint32_t bits, uint32_t channels)
 {
   if (channels == 1) return 65536u;
@@ -560,6 +562,17 @@ AADApiResult decode_plan_init(const struct AADHeaderInfo *format, int32_t has_fi
       args->pcm_aligned16 = 0;
       break;
     }
+  /* ... and its 3-bit rows want every block's code bytes at the same offset inside a granule (64 bytes mono, 128 stereo): all
+   * images start at the same offset inside one, and so does every block of an image */
+  {
+    const uint32_t granule = h.num_channels == 1 ? 64u : 128u;
+    args->code_phase_uniform = (h.block_size % granule == 0) ? 1 : 2; /* 2: one-block streams only (checked at launch) */
+    for (uint32_t i = 1; i < num_streams; i++)
+      if ((streams[i].data_offset - streams[0].data_offset) % granule != 0) {
+        args->code_phase_uniform = 0;
+        break;
+      }
+  }
   /* Dense stereo 4-/2-bit decode opens every block with a 16-frame chunk, so its stores are whole
    * 64-byte granules exactly when every block's first frame is 64-byte aligned: a uniform layout
    * whose stream pitch and block length (in PCM bytes) are multiples of 64.  Only then are they

@@ -1,7 +1,7 @@
 """The sector-tiled dense kernels (aad_amd/csrc/aad_decode_tiled.hip.h): device-resident plans whose PCM is
 16-byte aligned - the layouts on which the host launches them when the mapping is "dense-tiled" (and, for
 chip-filling batches, "auto") - against the oracle and against the per-lane dense kernels, bit for bit.
-Covered: 4- and 2-bit codes x mono / stereo x M/S, uniform tables (the table-free path) and shuffled ones,
+Covered: 4-, 3- and 2-bit codes (3-bit: image pitches a multiple of the granule, any common phase) x mono / stereo x M/S, uniform tables (the table-free path) and shuffled ones,
 images at every byte phase (0..127: the code bytes' phase inside a sector is what the tiles absorb), one to
 several blocks per stream with ragged last blocks, streams shorter than a chunk, odd block sizes, images cut
 short (missing bytes decode as zero), more rows than one wave and fewer than one."""
@@ -39,23 +39,24 @@ def _decode_with(engine, mapping, header, desc, d_img, n_pcm):
         engine.set_mapping("auto")
 
 
-def _layout(rng, lengths, sizes, ch, uniform, pad_dat):
-    """stream table with every PCM start on a 16-byte boundary (8 int16) and images at byte phase pad_dat"""
+def _layout(rng, lengths, sizes, ch, uniform, pad_dat, gran=1):
+    """stream table with every PCM start on a 16-byte boundary (8 int16) and images at byte phase pad_dat; gran: the images'
+    pitch is a multiple of it (3-bit rows take the tiled kernel only when all code bytes share their phase inside a granule)"""
     streams = len(lengths)
     d = np.zeros(streams, dtype=STREAM_DESC_DTYPE)
     order = list(range(streams)) if uniform else list(rng.permutation(streams))
     pitch_pcm = -(-(max(lengths) * ch + int(rng.integers(0, 40))) // 8) * 8
-    pitch_dat = max(sizes) + int(rng.integers(0, 70))
+    pitch_dat = -(-(max(sizes) + int(rng.integers(0, 70))) // gran) * gran
     pos_p, pos_d = 8 * int(rng.integers(0, 9)), pad_dat
     for slot in order:
         d["pcm_offset"][slot], d["data_offset"][slot] = pos_p, pos_d
         d["data_size"][slot], d["num_samples"][slot] = sizes[slot], lengths[slot]
         pos_p += pitch_pcm if uniform else -(-(lengths[slot] * ch + int(rng.integers(0, 30))) // 8) * 8
-        pos_d += pitch_dat if uniform else sizes[slot] + int(rng.integers(0, 90))
+        pos_d += pitch_dat if uniform else -(-(sizes[slot] + int(rng.integers(0, 90))) // gran) * gran
     return d, pos_p, pos_d
 
 
-@pytest.mark.parametrize("bits", [4, 2])
+@pytest.mark.parametrize("bits", [4, 3, 2])
 @pytest.mark.parametrize("channels", [1, 2])
 @pytest.mark.parametrize("uniform", [True, False])
 def test_tiled_decoder_matches_oracle_and_dense(engine, bits, channels, uniform):
@@ -64,6 +65,8 @@ def test_tiled_decoder_matches_oracle_and_dense(engine, bits, channels, uniform)
     for rep in range(10):
         ms = bool(channels == 2 and rep % 3 == 1)
         mbs = int(rng.choice([1024, 1024, 1024, 512, 300, 2048, 777]))
+        if bits == 3 and rep % 2 == 0:
+            mbs = int(rng.choice([1024, 512, 2048]))  # multi-block 3-bit streams stay on the tiled kernel when the block size is a granule multiple
         rc, block_size, spb = ob.geometry(mbs, channels, bits)
         assert rc == 0
         streams = int(rng.choice([1, 3, 31, 32, 33, 64, 65, 130]))
@@ -81,7 +84,7 @@ def test_tiled_decoder_matches_oracle_and_dense(engine, bits, channels, uniform)
                 last = 31 + (blocks - 1) * block_size
                 keep = last + 18 * channels + int(rng.integers(0, max(1, sizes[i] - last - 18 * channels)))
                 sizes[i] = min(sizes[i], keep)
-        d, n_pcm, n_dat = _layout(rng, lengths, sizes, channels, uniform, int(rng.integers(0, 128)))
+        d, n_pcm, n_dat = _layout(rng, lengths, sizes, channels, uniform, int(rng.integers(0, 128)), 64 * channels if bits == 3 else 1)
         flat = np.zeros(n_dat + 256, dtype=np.uint8)
         for i, w in enumerate(images):
             o = int(d["data_offset"][i])
@@ -104,12 +107,12 @@ def test_tiled_decoder_matches_oracle_and_dense(engine, bits, channels, uniform)
                 assert np.array_equal(got[:blocks_ok * spb], want[:blocks_ok * spb]), (bits, channels, uniform, rep, mbs, i, "cut")
 
 
-@pytest.mark.parametrize("bits,channels", [(4, 2), (4, 1), (2, 2), (2, 1)])
+@pytest.mark.parametrize("bits,channels", [(4, 2), (4, 1), (3, 2), (3, 1), (2, 2), (2, 1)])
 def test_tiled_decoder_chip_filling_uniform_batch(engine, bits, channels):
     """the shape bench.py's `saturated` leg runs (one-block streams, images pitched at multiples of 64 bytes), big enough
     for "auto" to take the tiled kernel: auto == dense-tiled == dense, and the decode reproduces the PCM's encode"""
     import torch
-    samples = {4: 1984, 2: 3960}[bits] // channels
+    samples = {4: 1984, 3: 2632, 2: 3960}[bits] // channels
     streams = (400000 if (bits, channels) == (4, 2) else 70000) // channels  # beyond the auto threshold of the 4-bit geometries
     param = make_parameter(channels, bits, 1024, 48000, False, 0)
     tile = torch.from_numpy(synth_pcm(500, samples, channels, seed=4321)).cuda()
