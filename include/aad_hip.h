@@ -70,7 +70,8 @@ const char *AADHip_ContextLastError(const struct AADHipContext *context);
 
 /* Launch options of a context.  Defaults: the environment variables AAD_HIP_MAPPING
  * (auto | dense | quad | quad-fused | dense-tiled), AAD_HIP_TRIAL_LANES (dual | single),
- * AAD_HIP_STAGING_THREADS (1..8) and AAD_HIP_TILE_KBYTES, read ONCE when the context is created; the library never calls getenv afterwards.  An option holds for every later
+ * AAD_HIP_STAGING_THREADS (1..8) and AAD_HIP_TILE_KBYTES, read ONCE when the context is created; the library does not read them
+ * again (the measurement aids of INTEGRATION.md section 4 - AAD_HIP_ENCODE_RING, ..._LDS_PAD - are not options and never change a byte).  An option holds for every later
  * ...Run / ...Batch call of the context; set it from the thread that owns the context. */
 enum AADHipOption {
   AAD_HIP_OPTION_LANE_MAPPING = 0, /* enum AADHipLaneMapping */
