@@ -13,6 +13,7 @@
 
 #include "aad_decode_split.hip.h"
 #include "aad_decode_split_launch.h"
+#include "aad_launch.h"
 
 namespace aad {
 
@@ -20,11 +21,11 @@ template <int BITS, bool LDSRES>
 static void launch_bits(const SplitDecodeArgs &sa, dim3 grid, dim3 block, hipStream_t stream)
 {
   if (sa.d.channels == 1)
-    hipLaunchKernelGGL((decode_split_kernel<BITS, 1, false, LDSRES>), grid, block, 0, stream, sa);
+    AAD_LAUNCH((decode_split_kernel<BITS, 1, false, LDSRES>), grid, block, 0, stream, sa);
   else if (sa.d.mid_side)
-    hipLaunchKernelGGL((decode_split_kernel<BITS, 2, true, LDSRES>), grid, block, 0, stream, sa);
+    AAD_LAUNCH((decode_split_kernel<BITS, 2, true, LDSRES>), grid, block, 0, stream, sa);
   else
-    hipLaunchKernelGGL((decode_split_kernel<BITS, 2, false, LDSRES>), grid, block, 0, stream, sa);
+    AAD_LAUNCH((decode_split_kernel<BITS, 2, false, LDSRES>), grid, block, 0, stream, sa);
 }
 
 bool decode_split_fits_lds(const DecodeArgs &args)

@@ -3,6 +3,7 @@
  */
 #include "aad_decode_tiled.hip.h"
 #include "aad_decode_tiled_launch.h"
+#include "aad_launch.h"
 
 namespace aad {
 
@@ -24,11 +25,11 @@ template <int BITS>
 static void launch_bits(const DecodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
 {
   if (a.channels == 1)
-    hipLaunchKernelGGL((decode_tiled_kernel<BITS, 1, false>), grid, block, 0, stream, a);
+    AAD_LAUNCH((decode_tiled_kernel<BITS, 1, false>), grid, block, 0, stream, a);
   else if (a.mid_side)
-    hipLaunchKernelGGL((decode_tiled_kernel<BITS, 2, true>), grid, block, 0, stream, a);
+    AAD_LAUNCH((decode_tiled_kernel<BITS, 2, true>), grid, block, 0, stream, a);
   else
-    hipLaunchKernelGGL((decode_tiled_kernel<BITS, 2, false>), grid, block, 0, stream, a);
+    AAD_LAUNCH((decode_tiled_kernel<BITS, 2, false>), grid, block, 0, stream, a);
 }
 
 bool launch_decode_tiled(const DecodeArgs &a, hipStream_t stream)

@@ -21,11 +21,16 @@
 #include "../../include/aad_hip.h"
 #include "aad_compare.hip.h"
 #include "aad_decode_split_launch.h"
+#include "aad_launch.h"
 #include "aad_decode_tiled_launch.h"
 #include "aad_decode.hip.h"
 #include "aad_encode.hip.h"
 #include "aad_format.h"
 #include "aad_hip_internal.h"
+
+namespace aad {
+thread_local LaunchSignal tl_launch_signal = {nullptr, nullptr}; /* aad_launch.h */
+}
 
 static_assert(sizeof(AADHipStreamDesc) == sizeof(aad::StreamDesc), "stream table layout");
 static_assert(sizeof(AADHipLaneState) == sizeof(aad::LaneStateRecord), "lane state layout");
@@ -82,6 +87,7 @@ struct AADHipContext {
   uint8_t *d_trial;
   uint64_t trial_capacity;
   /* AADHip_ContextSetOption; the defaults come from the environment ONCE, at creation */
+  aad::LaunchSignal signal_next; /* AADHip_ContextSignalNextRun: the events the next plan run records around its work (one-shot) */
   int32_t lane_mapping; /* enum AADHipLaneMapping */
   int32_t trial_lanes;  /* enum AADHipTrialLanes */
   int32_t compare_sequential; /* AAD_HIP_OPTION_COMPARE_ORDER: the -c sums always in the reference's order */
@@ -240,11 +246,11 @@ template <int BITS, bool TRIALS>
 bool launch_encode_ring(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream, unsigned lds_pad)
 {
   if (a.channels == 1)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::encode_streams_kernel<BITS, 1, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
   else if (a.channels == 2 && a.mid_side)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::encode_streams_kernel<BITS, 2, true, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
   else if (a.channels == 2)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::encode_streams_kernel<BITS, 2, false, false, TRIALS, false, true>), grid, block, lds_pad, stream, a);
   else
     return false;
   return true;
@@ -267,13 +273,13 @@ template <int BITS, bool QUAD, bool TRIALS, bool DUAL>
 void launch_encode_mapped(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStream_t stream, unsigned lds_pad = 0)
 {
   if (a.channels == 1)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 1, false, QUAD, TRIALS, DUAL>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::encode_streams_kernel<BITS, 1, false, QUAD, TRIALS, DUAL>), grid, block, lds_pad, stream, a);
   else if (a.channels == 2 && a.mid_side)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, true, QUAD, TRIALS, DUAL>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::encode_streams_kernel<BITS, 2, true, QUAD, TRIALS, DUAL>), grid, block, lds_pad, stream, a);
   else if (a.channels == 2)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 2, false, QUAD, TRIALS, DUAL>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::encode_streams_kernel<BITS, 2, false, QUAD, TRIALS, DUAL>), grid, block, lds_pad, stream, a);
   else if constexpr (!QUAD)
-    hipLaunchKernelGGL((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS, false>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::encode_streams_kernel<BITS, 0, false, false, TRIALS, false>), grid, block, lds_pad, stream, a);
 }
 
 /* Occupancy cap of the dense 4-bit encoders on chip-filling batches: unused dynamic LDS up to 80 KB per workgroup, so that a
@@ -367,26 +373,26 @@ void launch_decode_mapped(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipSt
 {
   const unsigned lds_pad = !QUAD && block.x == 256u ? dense_decode_lds_pad(a.total_blocks * a.channels, a.channels, a.bits) : 0u;
   if (a.channels == 1)
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 1, false, QUAD>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::decode_blocks_kernel<BITS, 1, false, QUAD>), grid, block, lds_pad, stream, a);
   else if (a.channels == 2 && a.mid_side) {
     if constexpr (!QUAD && BITS != 3) {
       if (a.stream_stores) {
-        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, false, true>), grid, block, lds_pad, stream, a);
+        AAD_LAUNCH((aad::decode_blocks_kernel<BITS, 2, true, false, true>), grid, block, lds_pad, stream, a);
         return;
       }
     }
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, true, QUAD>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::decode_blocks_kernel<BITS, 2, true, QUAD>), grid, block, lds_pad, stream, a);
   } else if (a.channels == 2) {
     if constexpr (!QUAD && BITS != 3) {
       if (a.stream_stores) {
-        hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, false, true>), grid, block, lds_pad, stream, a);
+        AAD_LAUNCH((aad::decode_blocks_kernel<BITS, 2, false, false, true>), grid, block, lds_pad, stream, a);
         return;
       }
     }
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 2, false, QUAD>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::decode_blocks_kernel<BITS, 2, false, QUAD>), grid, block, lds_pad, stream, a);
   }
   else if constexpr (!QUAD)
-    hipLaunchKernelGGL((aad::decode_blocks_kernel<BITS, 0, false, false>), grid, block, lds_pad, stream, a);
+    AAD_LAUNCH((aad::decode_blocks_kernel<BITS, 0, false, false>), grid, block, lds_pad, stream, a);
 }
 
 /* Quad decode runs its two strands on different lanes (aad_decode_split.hip.h) unless
@@ -584,6 +590,25 @@ AADApiResult decode_plan_init(const struct AADHeaderInfo *format, int32_t has_fi
 }
 
 /* launch with fully populated arguments (device pointers set) on the context's stream */
+/* AADHip_ContextSignalNextRun: the pending events, taken by the plan run that starts now ... */
+aad::LaunchSignal take_signal(AADHipContext *ctx)
+{
+  const aad::LaunchSignal s = ctx->signal_next;
+  ctx->signal_next = aad::LaunchSignal{nullptr, nullptr};
+  return s;
+}
+/* ... and settled when it ends: a run that launched its kernel has handed the events to it (aad_launch.h); one that launched
+ * nothing (an empty plan) records them behind whatever the stream holds; a failed run leaves them unrecorded */
+AADApiResult finish_signal(AADHipContext *ctx, const aad::LaunchSignal &signal, AADApiResult rc)
+{
+  const bool taken = aad::tl_launch_signal.start == nullptr && aad::tl_launch_signal.stop == nullptr;
+  aad::tl_launch_signal = aad::LaunchSignal{nullptr, nullptr};
+  if (taken || rc != AAD_APIRESULT_OK) return rc;
+  if (signal.start != nullptr && !hip_ok(ctx, hipEventRecord(signal.start, ctx->stream), "hipEventRecord")) return AAD_APIRESULT_NG;
+  if (signal.stop != nullptr && !hip_ok(ctx, hipEventRecord(signal.stop, ctx->stream), "hipEventRecord")) return AAD_APIRESULT_NG;
+  return rc;
+}
+
 AADApiResult run_encode(AADHipContext *ctx, const aad::EncodeArgs &args)
 {
   if (args.num_streams == 0) return AAD_APIRESULT_OK;
@@ -708,6 +733,7 @@ AADApiResult AADHip_ContextCreate(int32_t device_index, void *hip_stream, struct
   ctx->residual_capacity = 0;
   ctx->d_trial = nullptr;
   ctx->trial_capacity = 0;
+  ctx->signal_next = aad::LaunchSignal{nullptr, nullptr};
   ctx->pool = nullptr;
   ctx->staging_threads = 0;
   ctx->tile_bytes = 0;
@@ -794,6 +820,13 @@ void AADHipInternal_ContextOptionsFromEnvironment(struct AADHipContext *ctx)
 
 int32_t AADHipInternal_ContextDevice(const struct AADHipContext *ctx) { return ctx->device; }
 
+AADApiResult AADHip_ContextSignalNextRun(struct AADHipContext *ctx, void *hip_start_event, void *hip_stop_event)
+{
+  if (ctx == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
+  ctx->signal_next = aad::LaunchSignal{static_cast<hipEvent_t>(hip_start_event), static_cast<hipEvent_t>(hip_stop_event)};
+  return AAD_APIRESULT_OK;
+}
+
 AADApiResult AADHip_ContextSetOption(struct AADHipContext *ctx, int32_t option, int32_t value)
 {
   if (ctx == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
@@ -876,15 +909,17 @@ AADApiResult AADHip_EncodePlanRun(struct AADHipEncodePlan *plan, const int16_t *
 {
   if (plan == nullptr || device_pcm == nullptr || device_data == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
   AADHipContext *ctx = plan->ctx;
-  if (plan->args.num_streams == 0) return AAD_APIRESULT_OK;
+  const aad::LaunchSignal signal = take_signal(ctx);
   DeviceGuard guard(ctx);
   if (!guard.ok) return AAD_APIRESULT_NG;
+  if (plan->args.num_streams == 0) return finish_signal(ctx, signal, AAD_APIRESULT_OK);
   aad::EncodeArgs a = plan->args;
   a.pcm = device_pcm;
   a.data = device_data;
   a.state = reinterpret_cast<const aad::LaneStateRecord *>(device_state);
   a.state_out = reinterpret_cast<aad::LaneStateRecord *>(device_state);
-  return run_encode(ctx, a);
+  aad::tl_launch_signal = signal; /* the run's one kernel takes it (aad_launch.h) */
+  return finish_signal(ctx, signal, run_encode(ctx, a));
 }
 
 /* ------------------------------------------------------------------------------- decode -- */
@@ -937,14 +972,16 @@ AADApiResult AADHip_DecodePlanRun(struct AADHipDecodePlan *plan, const uint8_t *
 {
   if (plan == nullptr || device_data == nullptr || device_pcm == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
   AADHipContext *ctx = plan->ctx;
-  if (plan->args.total_blocks == 0) return AAD_APIRESULT_OK;
+  const aad::LaunchSignal signal = take_signal(ctx);
   DeviceGuard guard(ctx);
   if (!guard.ok) return AAD_APIRESULT_NG;
+  if (plan->args.total_blocks == 0) return finish_signal(ctx, signal, AAD_APIRESULT_OK);
   aad::DecodeArgs a = plan->args;
   a.data = device_data;
   a.pcm = device_pcm;
   if ((reinterpret_cast<uintptr_t>(device_pcm) & 63u) != 0) a.stream_stores = 0;
-  return run_decode(ctx, a);
+  aad::tl_launch_signal = signal;
+  return finish_signal(ctx, signal, run_decode(ctx, a));
 }
 
 } /* extern "C" */
@@ -1772,12 +1809,20 @@ AADApiResult AADHip_ReconstructPlanRun(struct AADHipReconstructPlan *plan, const
   if (output_kind != AAD_HIP_RECONSTRUCT_DECODED && output_kind != AAD_HIP_RECONSTRUCT_RESIDUAL)
     return AAD_APIRESULT_INVALID_ARGUMENT;
   AADHipContext *ctx = plan->ctx;
-  if (plan->args.num_streams == 0) return AAD_APIRESULT_OK;
+  /* a reconstruction is several kernels: pending AADHip_ContextSignalNextRun events are recorded in front of the first and
+   * behind the last of them */
+  const aad::LaunchSignal signal = take_signal(ctx);
+  if (signal.start != nullptr && !hip_ok(ctx, hipEventRecord(signal.start, ctx->stream), "hipEventRecord")) return AAD_APIRESULT_NG;
+  auto done = [&](AADApiResult r) -> AADApiResult {
+    if (r == AAD_APIRESULT_OK && signal.stop != nullptr && !hip_ok(ctx, hipEventRecord(signal.stop, ctx->stream), "hipEventRecord")) return AAD_APIRESULT_NG;
+    return r;
+  };
+  if (plan->args.num_streams == 0) return done(AAD_APIRESULT_OK);
   AADApiResult rc = AADHip_EncodePlanRun(plan->encode, device_pcm, device_data, nullptr);
   if (rc != AAD_APIRESULT_OK) return rc;
   rc = AADHip_DecodePlanRun(plan->decode, device_data, device_out);
   if (rc != AAD_APIRESULT_OK) return rc;
-  if (device_stats == nullptr && output_kind == AAD_HIP_RECONSTRUCT_DECODED) return AAD_APIRESULT_OK;
+  if (device_stats == nullptr && output_kind == AAD_HIP_RECONSTRUCT_DECODED) return done(AAD_APIRESULT_OK);
   DeviceGuard guard(ctx);
   if (!guard.ok) return AAD_APIRESULT_NG;
   aad::CompareArgs a = plan->args;
@@ -1791,7 +1836,7 @@ AADApiResult AADHip_ReconstructPlanRun(struct AADHipReconstructPlan *plan, const
   hipLaunchKernelGGL(aad::compare_segments_kernel, dim3((unsigned)a.total_segments), dim3(aad::kCompareThreads), 0, ctx->stream, a);
   if (device_stats)
     hipLaunchKernelGGL(aad::compare_finish_kernel, dim3(a.num_streams), dim3(64), 0, ctx->stream, a);
-  return hip_ok(ctx, hipGetLastError(), "compare launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG;
+  return done(hip_ok(ctx, hipGetLastError(), "compare launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG);
 }
 
 AADApiResult AADHip_ReconstructBatch(struct AADHipContext *ctx, const struct AADEncodeParameter *parameter,

@@ -70,6 +70,13 @@ class Engine:
         except Exception:
             pass
 
+    def signal_next(self, stop, start=None):
+        """stop / start: HipEvent (or None) - recorded when the work of the NEXT plan run on this engine is done / starts,
+        carried by the run's own kernel dispatch instead of packets around it (AADHip_ContextSignalNextRun)"""
+        _check("AADHip_ContextSignalNextRun",
+               self.lib.AADHip_ContextSignalNextRun(self._ctx, start.handle if start is not None else None,
+                                                    stop.handle if stop is not None else None))
+
     def last_error(self):
         return (self.lib.AADHip_ContextLastError(self._ctx) or b"").decode()
 
@@ -308,6 +315,71 @@ class DecodePlan:
             pass
 
 
+class HipEvent:
+    """A hipEvent_t of our own (timing disabled): what AADHip_ContextSignalNextRun takes and hipStreamWaitEvent waits for.
+    torch.cuda.Event cannot wrap a foreign handle and creates its own lazily, hence the few runtime calls made directly."""
+    _hip = None
+
+    @classmethod
+    def runtime(cls):
+        if cls._hip is None:
+            # THE runtime this process already runs on (torch's / libaad_hip.so's): a second copy would not know our streams
+            path = "libamdhip64.so"
+            try:
+                with open("/proc/self/maps") as maps:
+                    for line in maps:
+                        if "libamdhip64.so" in line:
+                            path = line.split()[-1]
+                            break
+            except OSError:
+                pass
+            hip = C.CDLL(path)
+            hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+            hip.hipEventDestroy.argtypes = [C.c_void_p]
+            hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+            hip.hipEventSynchronize.argtypes = [C.c_void_p]
+            hip.hipEventQuery.argtypes = [C.c_void_p]
+            hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+            cls._hip = hip
+        return cls._hip
+
+    def __init__(self, timing=False):
+        self.handle = C.c_void_p()
+        rc = self.runtime().hipEventCreateWithFlags(C.byref(self.handle), 0x0 if timing else 0x2)  # hipEventDisableTiming
+        if rc != 0:
+            raise RuntimeError("hipEventCreateWithFlags failed (%d)" % rc)
+
+    def wait_on(self, stream):
+        """stream: a torch.cuda.Stream - everything queued on it afterwards waits for this event"""
+        rc = self.runtime().hipStreamWaitEvent(C.c_void_p(stream.cuda_stream), self.handle, 0)
+        if rc != 0:
+            raise RuntimeError("hipStreamWaitEvent failed (%d)" % rc)
+
+    def elapsed_ms(self, stop):
+        """milliseconds from this (start) event to `stop`, both created with timing=True and both complete"""
+        ms = C.c_float()
+        rc = self.runtime().hipEventElapsedTime(C.byref(ms), self.handle, stop.handle)
+        if rc != 0:
+            raise RuntimeError("hipEventElapsedTime failed (%d)" % rc)
+        return float(ms.value)
+
+    def synchronize(self):
+        rc = self.runtime().hipEventSynchronize(self.handle)
+        if rc != 0:
+            raise RuntimeError("hipEventSynchronize failed (%d)" % rc)
+
+    def close(self):
+        if self.handle:
+            self.runtime().hipEventDestroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class EncodeDecodePipeline:
     """Encode on one context, decode on another: the encode of step k+1 runs while step k decodes.
 
@@ -315,7 +387,9 @@ class EncodeDecodePipeline:
     CUs with either kernel) the two kernels of consecutive steps share the device instead of taking
     turns.  Two streams ordered by events; the .aad images go through a ring of buffers so that an
     encode never overwrites what a decode still reads (one wait per half ring: the decode stream runs
-    in order).  Every step encodes its whole batch and decodes exactly what it encoded; `pcm` and `out`
+    in order).  The "encoded" events ride on the encode kernels' own dispatch packets (Engine.signal_next): an
+    event recorded BEHIND every encode costs the encode queue 3 us per step (tools/experiments/launch_gap_probe.py).
+    Every step encodes its whole batch and decodes exactly what it encoded; `pcm` and `out`
     are the caller's and must stay untouched until the step's kernels have run."""
 
     def __init__(self, enc_engine, dec_engine, param, streams, samples, ring=8):
@@ -333,29 +407,25 @@ class EncodeDecodePipeline:
         torch.cuda.synchronize()
         self.header = parse_header(bytes(self.images[0][0, :31].cpu().numpy()))
         self.dec = dec_engine.uniform_decode_plan(self.header, streams, self.enc.stride, self.enc.image_size)
-        self.encoded = [torch.cuda.Event() for _ in range(ring)]
+        self.encoded = [HipEvent() for _ in range(ring)]
         self.decoded = [torch.cuda.Event() for _ in range(ring)]
 
     def step(self, pcm, out, timing=None):
-        """timing: four timing events -> encode start / end (encode stream), decode start / end (decode stream)"""
+        """timing: four HipEvent(timing=True) -> start / end of the encode kernel, start / end of the decode kernel, carried by
+        the kernels' own dispatches like the ordering events (elapsed_ms between a pair = the kernel's own duration)"""
         k, ring = self.k, self.ring
         self.k += 1
         b = k % ring
         s_enc, s_dec = self.enc_engine.stream, self.dec_engine.stream
         if k >= ring and k % (ring // 2) == 0:  # covers the half ring of encodes that follows
             s_enc.wait_event(self.decoded[(k - ring // 2 - 1) % ring])
-        if timing is not None:
-            timing[0].record(s_enc)
+        encoded = self.encoded[b] if timing is None else timing[1]
+        self.enc_engine.signal_next(encoded, start=None if timing is None else timing[0])
         self.enc.run(pcm, self.images[b], None, ordered=False)
+        encoded.wait_on(s_dec)
         if timing is not None:
-            timing[1].record(s_enc)
-        self.encoded[b].record(s_enc)
-        s_dec.wait_event(self.encoded[b])
-        if timing is not None:
-            timing[2].record(s_dec)
+            self.dec_engine.signal_next(timing[3], start=timing[2])
         self.dec.run(self.images[b], out, ordered=False)
-        if timing is not None:
-            timing[3].record(s_dec)
         self.decoded[b].record(s_dec)
         return self.images[b]
 
@@ -363,6 +433,8 @@ class EncodeDecodePipeline:
         self.torch.cuda.synchronize()
         self.enc.close()
         self.dec.close()
+        for e in self.encoded:
+            e.close()
 
 
 def parse_header(data):

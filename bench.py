@@ -212,21 +212,19 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
 
         def step(events=None):
             if events is not None:
-                events[0].record()
+                engine.signal_next(events[1], start=events[0])
             enc.run(pcm, img, None)
             if events is not None:
-                events[1].record()
-                events[2].record()
+                engine.signal_next(events[3], start=events[2])
             dec.run(img, out)
-            if events is not None:
-                events[3].record()
 
     for _ in range(warmup):
         step()
-    # HIP events bracket the two kernels on every `event_every`-th step of the timed region (each
-    # record is a packet on the stream; bracketing every step would add ~2 % to a 100 us step)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] if k % event_every == 0 else None
-           for k in range(steps)]
+    # HIP events time the two kernels on every `event_every`-th step of the timed region.  They ride on the kernels' own
+    # dispatch packets (AADHip_ContextSignalNextRun: start / stop event of hipExtLaunchKernelGGL): the elapsed time of a pair
+    # is the kernel's duration as rocprofv3 reports it, and the queue sees no packet more than on an untimed step
+    from aad_amd.engine import HipEvent
+    evs = [[HipEvent(timing=True) for _ in range(4)] if k % event_every == 0 else None for k in range(steps)]
     timed = [e for e in evs if e is not None]
     group = world > 1 or collective  # barriers and the MAX over ranks run whenever a process group is up
     regions, enc_sum, dec_sum, n_ev = [], 0.0, 0.0, 0
@@ -251,8 +249,8 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         regions.append(dt)
-        enc_sum += sum(e[0].elapsed_time(e[1]) for e in timed)
-        dec_sum += sum(e[2].elapsed_time(e[3]) for e in timed)
+        enc_sum += sum(e[0].elapsed_ms(e[1]) for e in timed)
+        dec_sum += sum(e[2].elapsed_ms(e[3]) for e in timed)
         n_ev += len(timed)
     ordered = sorted(regions)
     dt = ordered[len(ordered) // 2] if len(ordered) % 2 else 0.5 * (ordered[len(ordered) // 2 - 1] + ordered[len(ordered) // 2])
@@ -715,10 +713,11 @@ def main():
             **{"algorithmic_bytes_per_launch": algorithmic,
                "bytes_per_sample": round(bps, 4), "samples_per_launch": n_step,
                "kernel_ms": round(m["enc_ms"], 5),
-               "kernel_ms_note": "HIP events on the encode stream, on every %d-th step of the timed regions; PIPELINED run: the decode "
-                                 "of the previous step occupies the other half of the chip meanwhile (`serial.encode_kernel_ms` is the "
-                                 "same kernel with the chip to itself)" % args.event_every if not args.serial else
-                                 "HIP events on the launch stream, on every %d-th step of the timed regions" % args.event_every,
+               "kernel_ms_note": "HIP events carried by the encode kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop events via "
+                                 "AADHip_ContextSignalNextRun: no packet around the kernel), on every %d-th step of the timed regions; "
+                                 "PIPELINED run: the decode of the previous step runs beside it (`serial.encode_kernel_ms` is the same "
+                                 "kernel with the chip to itself)" % args.event_every if not args.serial else
+                                 "HIP events carried by the kernel's own dispatch packet, every %d-th step" % args.event_every,
                "valu": valu_fields(stamp_e, note_e, m["enc_ms"], samples, "encode"),
                "decode_kernel": dict({"kernel": (stamp_d or {}).get("kernel", "aad::decode_split_kernel<4> (quad batches) / aad::decode_blocks_kernel<4> (dense)"),
                                       "achieved": round(dec_gbs, 3), "frac": round(dec_gbs / HBM_PEAK_GBS, 6), "kernel_ms": round(m["dec_ms"], 5),

@@ -68,6 +68,17 @@ AADApiResult AADHip_ContextSynchronize(struct AADHipContext *context);
 /* text of the last HIP failure seen by this context ("" if none); valid until the next call */
 const char *AADHip_ContextLastError(const struct AADHipContext *context);
 
+/* Cross-stream ordering and kernel timing without packets of their own.  `hip_start_event` / `hip_stop_event` (hipEvent_t the
+ * caller owns; either may be NULL, both NULL withdraws) are recorded when the work of the NEXT AADHip_EncodePlanRun /
+ * AADHip_DecodePlanRun / AADHip_ReconstructPlanRun call on this context starts / is done - one-shot: the run takes them.  An
+ * encode or decode plan run is one kernel, and the events ride on that kernel's own dispatch (hipExtLaunchKernelGGL's start and
+ * stop events) instead of on barrier packets around it: a hipEventRecord behind every launch of a back-to-back sequence costs
+ * the queue 2.9 us per launch on MI355X, the attached event nothing (profiles/r03_microbench_event_gap.txt), and
+ * hipEventElapsedTime between the two is the kernel's own duration.  Another stream waits for the stop event with
+ * hipStreamWaitEvent as usual.  A run that fails leaves the events unrecorded; the host-memory calls (...Batch, the legacy API)
+ * do not look at them. */
+AADApiResult AADHip_ContextSignalNextRun(struct AADHipContext *context, void *hip_start_event, void *hip_stop_event);
+
 /* Launch options of a context.  Defaults: the environment variables AAD_HIP_MAPPING
  * (auto | dense | quad | quad-fused | dense-tiled), AAD_HIP_TRIAL_LANES (dual | single),
  * AAD_HIP_STAGING_THREADS (1..8) and AAD_HIP_TILE_KBYTES, read ONCE when the context is created; the library does not read them

@@ -19,12 +19,16 @@ def masked_stream(torch, hip, words):
     return torch.cuda.ExternalStream(s.value)
 
 
-def run(torch, streams_pair, label, steps=200, regions=7):
+def run(torch, streams_pair, label, steps=200, regions=7, dec_mapping=None, enc_mapping=None):
     from aad_amd.capi import make_parameter
     from aad_amd.engine import Engine, EncodeDecodePipeline
     from aad_amd.synth import synth_pcm
     param = make_parameter(2, 4, 1024, 48000, False, 0)
     e1, e2 = Engine(0, stream=streams_pair[0]), Engine(0, stream=streams_pair[1])
+    if dec_mapping:
+        e2.set_mapping(dec_mapping)
+    if enc_mapping:
+        e1.set_mapping(enc_mapping)
     pcm = torch.from_numpy(synth_pcm(1000, 992, 2, seed=1234)).cuda()
     out = torch.zeros_like(pcm)
     pipe = EncodeDecodePipeline(e1, e2, param, 1000, 992, ring=16)
@@ -32,7 +36,8 @@ def run(torch, streams_pair, label, steps=200, regions=7):
         pipe.step(pcm, out)
     torch.cuda.synchronize()
     times = []
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    from aad_amd.engine import HipEvent
+    ev = [HipEvent(timing=True) for _ in range(4)]
     enc_k, dec_k = [], []
     for _ in range(regions):
         import time
@@ -42,8 +47,8 @@ def run(torch, streams_pair, label, steps=200, regions=7):
             if k % 50 == 25:
                 pipe.step(pcm, out, timing=ev)
                 torch.cuda.synchronize()
-                enc_k.append(ev[0].elapsed_time(ev[1]))
-                dec_k.append(ev[2].elapsed_time(ev[3]))
+                enc_k.append(ev[0].elapsed_ms(ev[1]))
+                dec_k.append(ev[2].elapsed_ms(ev[3]))
             else:
                 pipe.step(pcm, out)
         torch.cuda.synchronize()
@@ -65,6 +70,11 @@ def main():
     words = (n + 31) // 32
     print("CUs", n)
     run(torch, (torch.cuda.Stream(), torch.cuda.Stream()), "unmasked")
+    if "--mappings" in sys.argv:
+        for dm in ("dense", "quad-fused", "quad"):
+            run(torch, (torch.cuda.Stream(), torch.cuda.Stream()), "decode mapping " + dm, dec_mapping=dm)
+        run(torch, (torch.cuda.Stream(), torch.cuda.Stream()), "unmasked again")
+        return
     full = (1 << n) - 1
     def split(mask):
         return [(mask >> (32 * i)) & 0xFFFFFFFF for i in range(words)]
