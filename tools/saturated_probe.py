@@ -41,7 +41,8 @@ def main():
     out = torch.zeros_like(pcm)
     dplan.run(images, out)
     torch.cuda.synchronize()
-    assert torch.equal(out[:1000], out[1000:2000]) if args.streams >= 2000 else True
+    if not os.environ.get("AAD_PROBE_NOCHECK"):  # destructive measurement builds decode garbage
+        assert torch.equal(out[:1000], out[1000:2000]) if args.streams >= 2000 else True
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     enc = dec = 0.0
     for _ in range(args.reps):
