@@ -231,8 +231,12 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
     # The K-step region is timed `repeats` times over (at least; more while less than `min_timed_s` of
     # timed work has accumulated, up to `max_repeats`): one region of the headline batch is ~1.5 ms at the
     # driver's K = 20, and a single such window moved by 6 % between two runs of the same build.
-    # Every region is exactly K steps between barrier + synchronize on both sides; the line reports the
-    # median region.  The stop rule uses the MAX-over-ranks times, so every rank runs the same count.
+    # Every region is exactly K steps between barrier + synchronize on both sides; a rank's time runs from the common start
+    # (behind the opening barrier) to the completion of its own last kernel (the closing synchronize), the region's time is
+    # the MAX over ranks of those, and the closing barrier follows - its own latency (a collective launch and a device
+    # synchronize, ~0.1 ms against a 1.4 ms region at K = 20) is not part of the K steps and would show up as a scaling
+    # loss between N = 1, which runs no collective, and N > 1.  The line reports the median region.  The stop rule uses
+    # the MAX-over-ranks times, so every rank runs the same count.
     while len(regions) < repeats or (sum(regions) < min_timed_s and len(regions) < max_repeats):
         torch.cuda.synchronize()
         if group:
@@ -241,9 +245,9 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
         for k in range(steps):
             step(evs[k])
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t0  # this rank's K steps, from the common start to its own last kernel
         if group:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+            dist.barrier()  # the closing bracket; the region's time is the MAX over ranks below, not this collective's latency on top
         if group:  # MAX over ranks
             t = torch.tensor([dt], dtype=torch.float64, device=pcm.device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -566,8 +570,8 @@ def config5_batched_files(engine, torch, dist, rank, world, files_per_rank=1250,
     t0 = time.perf_counter()
     res = codec.encode_sharded_device(param, table, cached, root=0, return_rows=True)
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0  # this rank's share (the root's includes the gather and the copy to the host); MAX over ranks below
     dist.barrier()
-    dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
