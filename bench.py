@@ -173,8 +173,12 @@ def measure_in_flight(torch, Engine, device, pcm, param, steps, warmup, n_step, 
             d.close()
     return {"workload": "the headline batch, several steps in flight (one encode + decode pipeline per step in flight, stepped in turn)",
             "unit": "Msamples/s", "steps": steps, "depths": rows,
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (the HIP runtime's default)"),
             "note": "not the headline: `value` above keeps ONE encode and one decode running; this shows the throughput of the same "
-                    "steps when the caller has independent batches to overlap (the chip is mostly idle on a 1000-stream step)"}
+                    "steps when the caller has independent batches to overlap (the chip is mostly idle on a 1000-stream step).  "
+                    "Streams beyond the runtime's hardware queues share one and serialise: two steps in flight (4 streams + the null "
+                    "stream) give 60 900 Msamples/s on the default 4 queues and 98 500 with GPU_MAX_HW_QUEUES=8; beyond that the "
+                    "single Python thread that launches everything is the limit"}
 
 
 def algorithmic_bytes_per_sample(channels, block_size, spb):

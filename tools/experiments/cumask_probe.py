@@ -83,6 +83,10 @@ def main():
     for label, a in (("low half / high half", low), ("even / odd", even), ("low 5/8 / high 3/8", (1 << (n * 5 // 8)) - 1)):
         sa, sb = masked_stream(torch, hip, split(a)), masked_stream(torch, hip, split(full & ~a))
         run(torch, (sa, sb), label)
+    # both kernels on the SAME half of the chip (fewer busy CUs - higher clocks? - but the encode waves share their CUs)
+    for label, a in (("both on the low half", low), ("both on the low 5/8", (1 << (n * 5 // 8)) - 1), ("both on the low 3/4", (1 << (n * 3 // 4)) - 1)):
+        sa, sb = masked_stream(torch, hip, split(a)), masked_stream(torch, hip, split(a))
+        run(torch, (sa, sb), label)
     run(torch, (torch.cuda.Stream(), torch.cuda.Stream()), "unmasked again")
 
 
