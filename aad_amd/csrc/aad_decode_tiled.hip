@@ -13,8 +13,10 @@ bool decode_tiled_applicable(const DecodeArgs &a)
   if (a.bits < 2 || a.bits > 4) return false;
   if (!a.pcm_aligned16) return false;
   /* every block of a stream starts on a piece boundary: the block length in PCM bytes is a multiple of 16 (mono 2-bit
-   * blocks of 1024 bytes hold 4028 samples = 8056 bytes: not) - or no stream has a second block */
-  if (((uint64_t)a.samples_per_block * a.channels * 2u) % 16u != 0 && a.total_blocks > a.num_streams) return false;
+   * blocks of 1024 bytes hold 4028 samples = 8056 bytes: 8 mod 16, which the kernel takes with a short lead chunk) - or no stream has a second block */
+  const uint64_t block_pcm_bytes = (uint64_t)a.samples_per_block * a.channels * 2u;
+  const bool odd8_ok = a.bits == 2 && a.channels == 1 && block_pcm_bytes % 16u == 8u; /* DecodeTile::kOdd8: a short lead chunk for every second block */
+  if (block_pcm_bytes % 16u != 0 && !odd8_ok && a.total_blocks > a.num_streams) return false;
   if ((reinterpret_cast<uintptr_t>(a.pcm) & 15u) != 0) return false;
   /* 3-bit rows: the code bytes of every block at the same offset inside their granule (aad_decode_tiled.hip.h "3-bit rows") */
   if (a.bits == 3 && !(a.code_phase_uniform == 1 || (a.code_phase_uniform == 2 && a.total_blocks <= a.num_streams))) return false;

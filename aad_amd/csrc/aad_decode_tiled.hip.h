@@ -59,6 +59,12 @@ struct DecodeTile {
   static constexpr int kLeadBytes = kLead * BITS / 8 * CHF;
   static constexpr int kShift = k3 ? 2 * kTaps * CHF : 0;      /* 3-bit: chunk j's PCM starts kShift + j * kPcmBytes into the block */
   static constexpr int kRaw = (kCb + 3) / 4 + 1;               /* aligned dwords that hold a chunk's code bytes at any byte phase */
+  /* mono 2-bit blocks are 8 mod 16 bytes of PCM long (4028 samples at 1024 bytes): every second block of a stream starts 8 bytes
+   * off the piece grid.  Such a row opens with a SHORT lead chunk - 4 verbatim + 8 decoded samples = 24 bytes, two code bytes -
+   * which puts its chunks on the grid (and on the same positions as its neighbours': theta + 24 and theta + 32 range over the same
+   * values), and the first piece of its first granule is half a piece (its upper 8 bytes). */
+  static constexpr bool kOdd8 = BITS == 2 && CHF == 1;
+  static constexpr int kShortLead = 8, kShortLeadBytes = kShortLead * BITS / 8;
   static constexpr int kLanesPerRow = kG / 16;                 /* lanes that cover one granule: 4 / 8 */
   static constexpr int kRowsPerInst = 64 / kLanesPerRow;       /* 16 / 8 */
   static constexpr int kInst = kRows / kRowsPerInst;           /* wave-level accesses per granule of every row: 4 */
@@ -189,21 +195,26 @@ __global__ void __launch_bounds__((64 * DecodeTile<BITS, CHF>::kWaves), 2) decod
   constexpr int US = Pack<BITS>::kUnitSamples, UB = Pack<BITS>::kUnitBytes;
   const uint32_t coded = n > (uint32_t)kTaps ? n - kTaps : 0;
   /* lead: the row's first samples go through the output ring - 4- / 2-bit: the lead chunk (4 verbatim + 12 decoded); 3-bit: the 4 verbatim */
-  const bool lead = k3 ? (n >= (uint32_t)kTaps) : (coded >= (uint32_t)T::kLead && avail >= body + T::kLeadBytes);
+  const uintptr_t pcm0 = reinterpret_cast<uintptr_t>(a.pcm + sd.pcm_offset + first * ch);
+  const uintptr_t out_base = pcm0 & ~(uintptr_t)(T::kG - 1);
+  /* a multiple of 16 (mono 2-bit: of 8, see kOdd8): the host only launches this kernel on such layouts */
+  const uint32_t theta = (uint32_t)(pcm0 - out_base);
+  const bool odd8 = T::kOdd8 && (theta & 8u) != 0;
+  const uint32_t lead_dec = odd8 ? (uint32_t)T::kShortLead : (uint32_t)T::kLead;          /* decoded samples of the lead chunk */
+  const uint32_t lead_bytes = odd8 ? (uint32_t)T::kShortLeadBytes : (uint32_t)T::kLeadBytes; /* ... and its code bytes */
+  const uint32_t tbase = odd8 ? theta - 8u : theta; /* chunk j's PCM sits at tbase + (j + 1) * kPcmBytes (3-bit: theta + kShift + j * ...) */
+  const bool lead = k3 ? (n >= (uint32_t)kTaps) : (coded >= lead_dec && avail >= body + lead_bytes);
   uint32_t full = 0; /* whole 16-sample chunks behind the lead chunk whose code bytes are all there */
   if (lead) {
-    full = (coded - T::kLead) / kChunk;
-    const uint32_t fit = (avail - body - T::kLeadBytes) / T::kCb;
+    full = (coded - lead_dec) / kChunk;
+    const uint32_t fit = (avail - body - lead_bytes) / T::kCb;
     full = full < fit ? full : fit;
   }
 
   /* ---- the row's place in memory, published for the lanes that move its granules */
-  const uintptr_t code0 = reinterpret_cast<uintptr_t>(src) + body + T::kLeadBytes; /* first code byte behind the lead chunk */
+  const uintptr_t code0 = reinterpret_cast<uintptr_t>(src) + body + lead_bytes; /* first code byte behind the lead chunk */
   const uintptr_t in_base = code0 & ~(uintptr_t)(T::kG - 1);
   const int32_t hdr_pos = (int32_t)(reinterpret_cast<uintptr_t>(src) - in_base); /* block start relative to granule 0 (<= 0 ... < kG) */
-  const uintptr_t pcm0 = reinterpret_cast<uintptr_t>(a.pcm + sd.pcm_offset + first * ch);
-  const uintptr_t out_base = pcm0 & ~(uintptr_t)(T::kG - 1);
-  const uint32_t theta = (uint32_t)(pcm0 - out_base); /* a multiple of 16: the host only launches this kernel on such layouts */
   if (c == 0) {
     RowMeta m;
     m.in_base = in_base;
@@ -213,7 +224,7 @@ __global__ void __launch_bounds__((64 * DecodeTile<BITS, CHF>::kWaves), 2) decod
     if (m.g_max < m.g_min) m.g_max = m.g_min;
     m.out_base = out_base;
     m.lo = theta;
-    m.hi = theta + (lead ? (k3 ? T::kShift + full * T::kPcmBytes : (1u + full) * T::kPcmBytes) : 0u);
+    m.hi = lead ? (k3 ? theta + T::kShift + full * T::kPcmBytes : tbase + (1u + full) * T::kPcmBytes) : theta;
     *reinterpret_cast<RowMeta *>(tile + T::kMetaOff + my_row * T::kMetaBytes) = m;
   }
   /* trip count of the wave: the longest row's */
@@ -272,6 +283,9 @@ __global__ void __launch_bounds__((64 * DecodeTile<BITS, CHF>::kWaves), 2) decod
       if (k3 && CHF == 1) { /* a mono 3-bit row ends 8 bytes into a piece */
         if (at >= mv_lo[i] && at + 16u <= mv_hi[i]) store_through(mv_out[i] + (uint64_t)t * T::kG, r[i]);
         else if (at >= mv_lo[i] && at < mv_hi[i]) *reinterpret_cast<u32x2 *>(mv_out[i] + (uint64_t)t * T::kG) = u32x2{r[i].x, r[i].y};
+      } else if (T::kOdd8) { /* a mono 2-bit row may START 8 bytes into a piece (its end is on the grid) */
+        if (at >= mv_lo[i] && at < mv_hi[i]) store_through(mv_out[i] + (uint64_t)t * T::kG, r[i]);
+        else if (at + 8u == mv_lo[i] && mv_lo[i] < mv_hi[i]) *reinterpret_cast<u32x2 *>(mv_out[i] + (uint64_t)t * T::kG + 8u) = u32x2{r[i].z, r[i].w}; /* (a row with nothing in the ring has hi == lo) */
       } else if (at >= mv_lo[i] && at < mv_hi[i]) {
         store_through(mv_out[i] + (uint64_t)t * T::kG, r[i]);
       }
@@ -362,7 +376,7 @@ __global__ void __launch_bounds__((64 * DecodeTile<BITS, CHF>::kWaves), 2) decod
     } else {
 #pragma unroll
       for (int h = 0; h < 2; h++)
-        *reinterpret_cast<u32x4 *>(out_ring + ((theta + x + (CHF == 1 ? 16u * h : 32u * h + 16u * c)) & kRingMask)) = o.v[h];
+        *reinterpret_cast<u32x4 *>(out_ring + ((tbase + x + (CHF == 1 ? 16u * h : 32u * h + 16u * c)) & kRingMask)) = o.v[h];
     }
   };
 
@@ -380,15 +394,24 @@ __global__ void __launch_bounds__((64 * DecodeTile<BITS, CHF>::kWaves), 2) decod
     }
   } else if (lead) {
     uint32_t w[2] = {0, 0};
-    fetch_raw(s_pos - T::kLeadBytes, raw);
-    unpack(raw, (uint32_t)(s_pos - T::kLeadBytes) & 3u, w);
+    fetch_raw(s_pos - (int32_t)lead_bytes, raw);
+    unpack(raw, (uint32_t)(s_pos - (int32_t)lead_bytes) & 3u, w);
     int32_t y[kChunk];
     y[0] = y0;
     y[1] = y1;
     y[2] = y2;
     y[3] = y3;
-    decode_chunk16<BITS, (k3 ? kChunk : T::kLead), true>(L, w, lds, y + kTaps, finish);
-    pending = pack_chunk_pcm<CHF, false>(y, c);
+    if (T::kOdd8 && odd8) { /* the short lead chunk: 4 + 8 samples = 24 bytes, at theta (8 mod 16): 8 + 16 bytes */
+#pragma unroll
+      for (int j = kTaps + T::kShortLead; j < kChunk; j++) y[j] = 0;
+      decode_chunk16<BITS, (T::kOdd8 ? T::kShortLead : kChunk), true>(L, w, lds, y + kTaps, finish);
+      const ChunkPcm o = pack_chunk_pcm<CHF, false>(y, c);
+      *reinterpret_cast<u32x2 *>(out_ring + (theta & kRingMask)) = u32x2{o.v[0].x, o.v[0].y};
+      *reinterpret_cast<u32x4 *>(out_ring + ((theta + 8u) & kRingMask)) = u32x4{o.v[0].z, o.v[0].w, o.v[1].x, o.v[1].y};
+    } else {
+      decode_chunk16<BITS, (k3 ? kChunk : T::kLead), true>(L, w, lds, y + kTaps, finish);
+      pending = pack_chunk_pcm<CHF, false>(y, c);
+    }
   }
   if (!lead) {
     if (n > 0) dst[0] = (int16_t)y0;
@@ -408,7 +431,7 @@ __global__ void __launch_bounds__((64 * DecodeTile<BITS, CHF>::kWaves), 2) decod
   /* 3-bit: the offset of the code bytes inside their granule, the same for every row of the batch (see "3-bit rows") */
   const uint32_t uphase = k3 ? (uint32_t)__builtin_amdgcn_readfirstlane(s_pos) : 0u;
   fetch_raw(pos, raw);
-  if (!k3 && lead) put_pcm(0, pending);
+  if (!k3 && lead && !odd8) put_pcm(0, pending);
   ChunkWalk wa, wb; /* the tables of the chunk in arithmetic and of the one behind it */
   int32_t idx_run = L.idxb; /* the step index runs a chunk ahead of the samples */
   if (0 < full) {
@@ -477,7 +500,7 @@ __global__ void __launch_bounds__((64 * DecodeTile<BITS, CHF>::kWaves), 2) decod
 
   /* ---- remaining units of the block, per lane: byte loads, bytes past the stream read as zero (decode_blocks_kernel) */
   {
-    const uint32_t done = lead ? T::kLead + full * kChunk : 0u;
+    const uint32_t done = lead ? lead_dec + full * kChunk : 0u;
     const uint32_t unit_stride = UB * ch;
     const uint32_t base = body + c * UB;
     for (uint32_t i = done; i < coded; i += US) {

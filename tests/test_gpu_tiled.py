@@ -95,7 +95,15 @@ def test_tiled_decoder_matches_oracle_and_dense(engine, bits, channels, uniform)
         hd = parse_header(images[0][:31])
         tiled = _decode_with(engine, "dense-tiled", hd, d, d_img, n_pcm + 64)
         dense = _decode_with(engine, "dense", hd, d, d_img, n_pcm + 64)
-        assert np.array_equal(tiled, dense), (bits, channels, uniform, rep, mbs, streams, lengths[:4], "tiled != dense (untouched bytes included)")
+        if not np.array_equal(tiled, dense):
+            bad = np.nonzero(tiled != dense)[0]
+            first = int(bad[0])
+            owner = max((i for i in range(streams) if int(d["pcm_offset"][i]) <= first), key=lambda i: int(d["pcm_offset"][i]), default=-1)
+            rel = first - int(d["pcm_offset"][owner]) if owner >= 0 else first
+            raise AssertionError((bits, channels, uniform, rep, mbs, streams, lengths[:4], "tiled != dense (untouched bytes included)",
+                                  "first bad int16", first, "count", int(bad.size), "stream", owner, "offset in stream", rel,
+                                  "block", rel // (spb * channels), "in block", rel % (spb * channels), "length", lengths[owner], "size", sizes[owner],
+                                  "tiled", tiled[first:first + 6].tolist(), "dense", dense[first:first + 6].tolist()))
         for i, w in enumerate(images):
             want = np.zeros((lengths[i], channels), dtype=np.int16)
             buf = np.frombuffer(w, dtype=np.uint8)[:sizes[i]].copy()
