@@ -128,6 +128,13 @@ def valu_fields(stamp, note, kernel_ms, samples_per_recurrence, role):
     if "SQ_ACTIVE_INST_VALU" in stamp and stamp.get("GRBM_GUI_ACTIVE"):
         # clock-independent: quad-cycles in which a SIMD issued VALU work / SIMD-cycles of the profiled launch
         v["valu_active_frac_pmc"] = round(stamp["SQ_ACTIVE_INST_VALU"] * 4.0 / SIMDS / (stamp["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    if stamp.get("GRBM_GUI_ACTIVE") and stamp.get("duration_ns") and waves > SIMDS:
+        # the shader clock the chip HELD during the profiled launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs; only meaningful
+        # when every XCD is busy for the whole launch): a chip-filling launch of these kernels runs at ~1.85 GHz, not at 2.4
+        clk = stamp["GRBM_GUI_ACTIVE"] / 8.0 / stamp["duration_ns"]
+        if 0.5 < clk <= CLOCK_GHZ * 1.02:
+            v["clock_ghz_measured"] = round(clk, 3)
+            v["frac_at_measured_clock"] = round(rate / (SIMDS * clk / mix), 5)
     if waves <= SIMDS:
         # fewer waves than SIMDs: each wave is alone on its SIMD and is offered an issue slot every ~4 cycles
         lone_peak = occupied * CLOCK_GHZ / LONE_WAVE_CYCLES_PER_INST
