@@ -215,10 +215,13 @@ struct NoFill {
  * different candidates side by side on different lanes of one wave - one instruction stream) */
 enum { kPassRmse = 0, kPassEncode = 1, kPassBoth = 2 };
 
-template <int BITS, int PASS, int FORMAT = kWide, typename Fill = NoFill>
+/* N: samples walked (sixteen; fewer for a block's last samples, see run_block's pipelined tail - their codes end up in the LOW
+ * bits of the last code word they reach) */
+template <int BITS, int PASS, int FORMAT = kWide, typename Fill = NoFill, int N = kChunk>
 __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C, const int32_t *x, int32_t xn0,
                                                     const char *lds, uint32_t *w, int32_t &qd_out, int64_t &sq, Fill fill = Fill())
 {
+  static_assert(N >= 1 && N <= kChunk, "at most a chunk");
   constexpr bool EMIT = PASS != kPassRmse, SUM = PASS != kPassEncode;
   auto sample = [&](int k) -> int32_t { /* sample k of this chunk (k = 16: first of the next), k compile-time */
     if (FORMAT == kPairs) {
@@ -232,7 +235,7 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
   int32_t p = C.p, d = C.d, m = C.m, idxj = C.j;
   const uint32_t copy = C.copy;
   float f = C.f;
-  static_for<0, kChunk>([&](auto jc) {
+  static_for<0, N>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     /* A */
     const uint32_t mag = min((uint32_t)__builtin_fmaf(__builtin_fabsf(f), __uint_as_float(e.z), __uint_as_float(e.y)),
@@ -288,7 +291,7 @@ __device__ __forceinline__ void encode_chunk16_quad(QuadLane &L, EncodeCarry &C,
     f = (float)d;
     m = d >> 31;
     pin(m);
-    if (j + 1 == kChunk) qd_out = qd;
+    if (j + 1 == N) qd_out = qd;
     __builtin_amdgcn_sched_barrier(0);
   });
   C.e = e;
@@ -1272,6 +1275,40 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
       }
       done = full * kChunk;
     }
+  }
+
+  if constexpr (QUAD && PASS != kPassRmse) { /* (kPassBoth: a whole number of units needs no padding, so measuring and encoding lanes walk the same samples) */
+    /* Pipelined tail (round 3).  A 1024-byte block's coded samples are 12 (4-bit: 988, 1980) or 8 (2-bit; 3-bit: one unit) past
+     * a multiple of sixteen, and encode_step - one sample at a time, its two table lookups in series, a load per sample - walked
+     * them at about a third of the chunk body's pace: ~3000 of a one-block kernel's 149 000 cycles.  A whole number of pack
+     * units goes through the chunk body instantiated for that many samples instead: the samples are fetched together, the
+     * recurrence is primed as at a block's start, the codes leave as unit bytes at the addresses the slow path writes. */
+    const uint32_t rest = coded - done;
+    auto tail = [&](auto nc) {
+      constexpr int N = decltype(nc)::value;
+      constexpr int cpw = Pack<BITS>::kCodesPerWord;
+      int32_t xt[kChunk];
+#pragma unroll
+      for (int j = 0; j < kChunk; j++) xt[j] = j < N ? src.at(first + kTaps + done + j) : 0;
+      EncodeCarry C;
+      encode_prime_quad<BITS>(L, C, xt[0], lds);
+      uint32_t w[2] = {0, 0};
+      encode_chunk16_quad<BITS, PASS, kWide, NoFill, N>(L, C, xt, 0, lds, w, last_qd, sq);
+      if (writer) {
+        uint8_t *up = body + (uint64_t)(done / US) * unit_stride + (uint64_t)c * UB;
+        static_for<0, N / US>([&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          constexpr int wi = (u * US) / cpw;                                   /* the code word the unit sits in */
+          constexpr int filled = (N - wi * cpw < cpw ? N - wi * cpw : cpw) * BITS; /* bits of that word that hold codes (low bits) */
+          constexpr int off = ((u * US) % cpw) * BITS;                         /* the unit's first bit, from the top of the filled part */
+#pragma unroll
+          for (int q = 0; q < UB; q++) up[(uint64_t)u * unit_stride + q] = (uint8_t)(w[wi] >> (filled - off - 8 * (q + 1)));
+        });
+      }
+      done += N;
+    };
+    if (rest == 12u && 12 % US == 0) tail(std::integral_constant<int, 12>());
+    else if (rest == 8u && 8 % US == 0) tail(std::integral_constant<int, 8>());
   }
 
   if constexpr (RING) {
