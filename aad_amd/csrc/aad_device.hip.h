@@ -239,15 +239,15 @@ template <int BITS, bool QUAD, int WIDE_STEP_SHIFT = 0, bool WIDE4 = false>
 __device__ __forceinline__ void stage_tables(char *lds)
 {
   constexpr int kShift = BITS - 1;
-  for (int i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) {
-    const float hr = __uint_as_float(c_half_recip_bits[i]);
+  auto put = [&](int i, uint32_t step_i, uint32_t recip_i) {
+    const float hr = __uint_as_float(recip_i);
     const float hs = hr * (float)(1 << kShift); /* exact power-of-two scaling */
-    reinterpret_cast<uint32_t *>(lds + kLdsStepOff)[i] = c_step_table[i];
+    reinterpret_cast<uint32_t *>(lds + kLdsStepOff)[i] = step_i;
     reinterpret_cast<float *>(lds + kLdsHrOff)[i] = hr;
     reinterpret_cast<float *>(lds + kLdsHsOff)[i] = hs;
     if (QUAD) {
       u32x4 e;
-      e.x = (uint32_t)c_step_table[i] << WIDE_STEP_SHIFT; /* the encoders want step << kWideStepShift, see encode_chunk16_quad */
+      e.x = step_i << WIDE_STEP_SHIFT; /* the encoders want step << kWideStepShift, see encode_chunk16_quad */
       e.y = __float_as_uint(hr);
       e.z = __float_as_uint(hs);
       e.w = 0;
@@ -262,6 +262,21 @@ __device__ __forceinline__ void stage_tables(char *lds)
         *reinterpret_cast<u32x4 *>(lds + kLdsWideOff + (i << 4)) = e;
       }
     }
+  };
+  static_assert(AAD_STEP_TABLE_LEN == 256, "four rounds of one wave");
+  if (blockDim.x == 64) {
+    /* one wave (the quad encoder of a lane-starved batch): its four rounds' table words are all requested before the first is
+     * used - round by round, each round waited for its own trip to the constant data */
+    uint32_t step_w[4], recip_w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      step_w[k] = c_step_table[threadIdx.x + 64 * k];
+      recip_w[k] = c_half_recip_bits[threadIdx.x + 64 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) put((int)threadIdx.x + 64 * k, step_w[k], recip_w[k]);
+  } else {
+    for (int i = threadIdx.x; i < AAD_STEP_TABLE_LEN; i += blockDim.x) put(i, c_step_table[i], c_half_recip_bits[i]);
   }
   const int16_t *dt = BITS == 4 ? c_delta4 : (BITS == 3 ? c_delta3 : c_delta2);
   if (threadIdx.x < (1 << BITS)) {
