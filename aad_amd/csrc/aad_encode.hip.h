@@ -917,7 +917,6 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         if (chunks > 2) rp += (uint64_t)kChunk * ch; /* rp: where chunk min(2, chunks - 1) starts - what the first chunk prefetches */
         encode_prime_quad<BITS>(L, C, (int32_t)(int16_t)b0.d[0], lds); /* both formats: sample 0 is the low half of dword 0 */
       }
-      AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
       /* The chunk-level work rides in the first DPP gap of the samples (see encode_chunk16_quad): the
        * loads of chunk k+2 in samples 0-3, then - stereo 4-bit, the BASELINE shape - the store of chunk
        * k-1's codes taken apart into its seven instructions, then the prefetch pointer.  Every tap of
@@ -973,7 +972,6 @@ __device__ __forceinline__ int64_t run_block(S &L, const SampleSource<MS> &src, 
         if (k + 1 < chunks) one(k + 1, b1, b2, b0);
         if (k + 2 < chunks) one(k + 2, b2, b0, b1);
       }
-      AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
       if constexpr (kStaged) { /* the last chunk's codes */
         if (chunks) {
           const uint32_t w[2] = {wp0, wp1};
@@ -1671,7 +1669,6 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
   const SampleSource<MS> src = {a.pcm + sd.pcm_offset, ch, c, sd.num_samples};
   uint8_t *out = a.data + sd.data_offset;
   const uint32_t total = sd.num_samples, spb = a.samples_per_block;
-  AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
 
   /* F: the complete per-channel state, the form block headers and the state records need;
    * between block boundaries the quad mapping spreads it over four lanes (S) */
@@ -1734,7 +1731,6 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
       if constexpr (QUAD) F = from_quad<kEncTM>(L); else F = L;
     }
     seed_history(F, src, first, n);
-    AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
     uint8_t *body = out + block_off + (uint64_t)kBlockHeaderBytesPerCh * ch;
     /* dense stereo 4-bit: code bytes 3 bytes into a 64-byte granule - the channel-1 lane holds the
      * header's last three bytes back for the first burst of code bytes (run_block) */
