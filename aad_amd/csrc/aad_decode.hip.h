@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(256) decode_blocks_kernel(DecodeArgs a)
   if (n) { /* block header - reference src/aad_decoder.c:364-380 */
     const uint8_t *hp = src + c * kBlockHeaderBytesPerCh;
     const uint32_t v = load_be16(hp);
-    H.idxb = min((int32_t)(v >> 4), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias;
+    H.idxb = min((int32_t)(v >> 4), (int32_t)kHeaderIdxMax) + kIdxBias;
     const uint32_t shift = v & 0xFu;
     H.w0 = (int32_t)((uint32_t)(int32_t)(int16_t)load_be16(hp + 2) << shift);
     H.h0 = (int16_t)load_be16(hp + 4);

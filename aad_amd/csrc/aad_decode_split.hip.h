@@ -113,7 +113,7 @@ __device__ __forceinline__ void residuals_for_recurrence(const SplitDecodeArgs &
   if (coded == 0) return;
 
   /* step index the block header carries - reference src/aad_decoder.c:364-366 */
-  int32_t carry = min((int32_t)(load_be16(blk.src + c * kBlockHeaderBytesPerCh) >> 4), (int32_t)AAD_STEP_INDEX_MAX) + kIdxBias;
+  int32_t carry = min((int32_t)(load_be16(blk.src + c * kBlockHeaderBytesPerCh) >> 4), (int32_t)kHeaderIdxMax) + kIdxBias;
   const uint32_t body = (uint32_t)kBlockHeaderBytesPerCh * ch + c * UB;
   const uint32_t unit_stride = UB * ch;
 

@@ -88,6 +88,12 @@ constexpr int kChunk = 16; /* samples per unrolled chunk: a multiple of every pa
  */
 constexpr int kIdxBias = 8;
 constexpr int kIdxMin = kIdxBias, kIdxMax = AAD_STEP_INDEX_MAX + kIdxBias;
+/* Largest step index a BLOCK HEADER may carry and still mean something in the reference: the 12-bit field is taken as it is
+ * (src/aad_decoder.c:365-366, no clamp), the first sample's step is T[(idx + 8) >> 4] (src/aad_tables.h:15,28) - slot 255 for
+ * 4081..4087 as for 4080 - and the index walk goes on from the UNCLAMPED value (clamp(idx + delta, 0, 4080), :31-43), so a
+ * header index of 4087 followed by a delta of -18 gives 4069, not 4062.  4088..4095 make the reference read past its
+ * 256-entry table (undefined there); they are taken as 4087 here. */
+constexpr int kHeaderIdxMax = AAD_STEP_INDEX_MAX + 7;
 constexpr int kLdsStepOff = 0, kLdsHrOff = 1024, kLdsHsOff = 2048;
 constexpr int kLdsCodeOff = 3072;
 constexpr int kLdsCodeShift = 3; /* log2 of the record size */

@@ -390,7 +390,10 @@ int aado_decode_block(const AadoHeader *hd, const uint8_t *block, size_t size,
     uint32_t v = get_be(p, 2);
     p += 2;
     lanes[c].idx = (int32_t)(v >> 4);
-    if (lanes[c].idx > AAD_STEP_INDEX_MAX) lanes[c].idx = AAD_STEP_INDEX_MAX; /* malformed input: the reference indexes past its table here */
+    /* The reference takes the 12-bit field as it is (:365-366).  4081..4087 still select the last table entry
+     * ((idx + 8) >> 4 = 255) and the walk continues from the unclamped value; 4088..4095 index past its
+     * 256-entry table (undefined there) and are taken as 4087 here. */
+    if (lanes[c].idx > AAD_STEP_INDEX_MAX + 7) lanes[c].idx = AAD_STEP_INDEX_MAX + 7;
     const uint32_t shift = v & 0xFu;
     for (int k = 0; k < AADO_TAPS; k++) {
       lanes[c].w[k] = (int32_t)((uint32_t)(int32_t)(int16_t)get_be(p, 2) << shift);
