@@ -132,7 +132,10 @@ __device__ __forceinline__ void residuals_for_recurrence(const SplitDecodeArgs &
       for (int t = 0; t < US; t++) code[u * US + t] = (acc >> (BITS * (US - 1 - t))) & ((1u << BITS) - 1u);
     }
     /* this chunk's index walk as one clamp function */
-    ClampAdd f = {0, kIdxMin, kIdxMax};
+    /* the identity: NO clamp of its own - a block header may carry an index above kIdxMax (up to kHeaderIdxMax, the
+     * reference takes the field as it is), and x -> clamp(x, lo, hi) in front of the first delta would cut it down before
+     * the delta is added (found by tests/test_gpu_bitstream_fuzz.py: header index 4087, first delta -14) */
+    ClampAdd f = {0, -(1 << 20), 1 << 20};
 #pragma unroll
     for (int j = 0; j < kChunk; j++) {
       if (j < (int)cnt) {
