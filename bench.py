@@ -3,6 +3,10 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches
 one rank per GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
+`--gpus N` means N: under a launcher it must equal WORLD_SIZE (anything else exits 2, no line); run plainly
+(`python bench.py --gpus 4`, no WORLD_SIZE) the script starts its own N ranks as a child process - before it has
+touched the GPU itself - and leaves with the child's exit code; under RCCL it refuses more ranks than the node has GPUs
+(`--backend gloo` rehearses N > 1 on one GPU).
 
 Headline workload (BASELINE.json configs[1]+[2], SURVEY.md section 8d "Config 2/3", primary form):
   1000 independent 48 kHz stereo 4-bit streams x 1 block (992 samples/channel) of the synthetic
@@ -14,7 +18,7 @@ no data-path collective: "scaling": "weak".
 
 Extra objects on the JSON line (N = 1 unless stated):
   roofline      the dominant kernel (encode_streams_kernel) against the HBM roof, from HIP events
-                recorded on the launch stream inside the timed region
+                carried by the kernels' own dispatch packets (AADHip_ContextSignalNextRun) inside the timed region
   trials2       the same batch with num_encode_trials = 2, the reference CLI's default (src/main.c:45-47)
   end_to_end    PCIe-inclusive figures for the same batch: pinned buffers + device plans, and the
                 host-memory C-ABI (AADHip_EncodeBatch / AADHip_DecodeBatch, pageable caller buffers)
@@ -22,9 +26,9 @@ Extra objects on the JSON line (N = 1 unless stated):
                 cfg4 8-channel 3-/2-bit x 10 000, cfg5's per-GPU shard 1250 files x 10 blocks - each
                 with kernel ms, Msamples/s, HBM-roof fraction and a bit-exact flag against the hashes
                 the compiled reference produced for the same corpus (tests/golden/manifest.json)
-  saturated     the same kernels on a batch big enough to fill the chip
+  saturated     the same kernels on a batch big enough to fill the chip (rank 0, any N)
   cpu_baseline  the compiled reference (oracle/_ref, kind "reference") or the oracle restatement
-                (kind "port") on ONE pinned host core, same batch, through a C loop
+                (kind "port") on ONE pinned host core, same batch, through a C loop (rank 0, any N)
   config5       (N > 1 only) BASELINE config 5's batched-file mode: RCCL broadcast of the job table,
                 1250 files per rank encoded device-resident, RCCL gather of the images to rank 0,
                 which checks them against the reference's hashes (aad_amd/batch.py)
@@ -607,9 +611,51 @@ def config5_batched_files(engine, torch, dist, rank, world, files_per_rank=1250,
                 includes="table broadcast excluded; shard encode + gather + device-to-host copy on rank 0 included")
 
 
+def launch_command(argv, gpus, port):
+    """the command `python bench.py --gpus N ...` turns into when it is run plainly (no WORLD_SIZE in the environment):
+    the driver's own launch line - one rank per GPU of ONE node under torch.distributed.run, rendezvous on 127.0.0.1"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(argv, gpus):
+    """Start the N ranks as a CHILD process and leave with its exit code.  Runs before anything in this process has
+    touched the GPU (torch is not even imported yet): a process that has initialised HIP must not exec or fork GPU
+    work.  Rank 0 of the child writes the one JSON line to the stdout it inherits from here."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    return subprocess.run(launch_command(argv, gpus, port), env=env).returncode
+
+
+def resolve_world(gpus, environ):
+    """--gpus N against the launcher's environment -> ("run", rank, local_rank, world) or ("launch", N) or ("error", text).
+    `--gpus N` MEANS N: a line with n_gpus != N is never printed."""
+    if gpus < 1:
+        return ("error", "--gpus must be at least 1")
+    if "WORLD_SIZE" not in environ:
+        return ("run", 0, 0, 1) if gpus == 1 else ("launch", gpus)
+    try:
+        world, rank, local = int(environ["WORLD_SIZE"]), int(environ.get("RANK", "0")), int(environ.get("LOCAL_RANK", "0"))
+    except ValueError:
+        return ("error", "WORLD_SIZE / RANK / LOCAL_RANK are not integers")
+    if world != gpus:
+        return ("error", "--gpus %d but the launcher started WORLD_SIZE=%d ranks: pass --gpus %d (or run `python bench.py --gpus %d` "
+                         "plainly and let it start its own ranks)" % (gpus, world, world, gpus))
+    if not 0 <= rank < world:
+        return ("error", "RANK=%d outside WORLD_SIZE=%d" % (rank, world))
+    return ("run", rank, local, world)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; run plainly with N > 1 the script starts its own N ranks "
+                                                         "(torch.distributed.run), under a launcher it must equal WORLD_SIZE")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=1000)
@@ -628,6 +674,14 @@ def main():
                     help="N = 1: skip the batched-file leg under a one-rank RCCL group (BASELINE config 5's code path with the collectives forced)")
     args = ap.parse_args()
 
+    plan = resolve_world(args.gpus, os.environ)
+    if plan[0] == "error":
+        sys.stderr.write("bench.py: %s\n" % plan[1])
+        raise SystemExit(2)
+    if plan[0] == "launch":
+        raise SystemExit(launch_ranks(sys.argv[1:], plan[1]))
+    _, rank, local, world = plan
+
     # Rank 0 owes the driver ONE line on stdout.  RCCL prints a version banner on stdout when its first communicator
     # comes up (seen on the GPU box: five lines in front of the JSON), so file descriptor 1 is pointed at stderr for
     # the whole run - native libraries included - and the line goes out through a saved duplicate at the end.
@@ -638,9 +692,9 @@ def main():
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.backend == "nccl" and torch.cuda.device_count() < world:  # counting devices does not initialise HIP
+        raise SystemExit("bench.py: --gpus %d under RCCL needs %d GPUs, this node shows %d (RCCL refuses two ranks on one device; "
+                         "--backend gloo rehearses N > 1 on fewer)" % (world, world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the AAD engine has no CPU path")
     local = local % torch.cuda.device_count()  # (a 1-GPU box can rehearse N>1 with --backend gloo)
@@ -787,7 +841,7 @@ def main():
         ]
         line["configs"] = [config_entry(engine, torch, dist, *c) for c in cfgs]
 
-    if not args.no_saturated and world == 1:
+    if not args.no_saturated and rank == 0:  # per-kernel figures of ONE GPU: rank 0 alone, no collective inside
         big_streams = args.saturated_streams  # 262144 stereo streams = 8192 waves = 8 per SIMD (dense mapping)
         reps = -(-big_streams // args.streams)
         big = pcm.repeat((reps, 1, 1))[:big_streams].contiguous()
@@ -859,11 +913,13 @@ def main():
         except Exception as e:  # noqa: BLE001 - reported, not raised
             line["config5"] = {"error": repr(e)[:400], "backend": "nccl", "world_size": 1}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:  # N > 1 too: the host cores are the same box's; the other ranks wait at the barrier below
         trials_list = [args.trials] + ([2] if extras and args.trials != 2 else [])
         cpu = cpu_baseline(pcm_np, bits, mbs, trials_list)
         line["cpu_baseline"] = cpu[args.trials]
         line["cpu_baseline"]["gpu_over_cpu"] = round(value / cpu[args.trials]["value"], 1)
+        if world > 1:
+            line["cpu_baseline"]["gpu_over_cpu_note"] = "whole job (%d GPUs) over ONE host core" % world
         if "trials2" in line and 2 in cpu:
             line["trials2"]["cpu_baseline"] = cpu[2]
             line["trials2"]["gpu_over_cpu"] = round(line["trials2"]["value"] / cpu[2]["value"], 1)
@@ -877,6 +933,7 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
+        dist.barrier()  # rank 0's CPU baseline and saturated leg end before any rank tears the group down
         dist.destroy_process_group()
 
 
