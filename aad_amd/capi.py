@@ -72,7 +72,7 @@ LEGACY_SYMBOLS = [
 ]
 HIP_SYMBOLS = [
     "AADHip_GetDeviceCount", "AADHip_ContextCreate", "AADHip_ContextDestroy", "AADHip_ContextSynchronize",
-    "AADHip_ContextLastError", "AADHip_ContextSignalNextRun", "AADHip_ContextSetOption", "AADHip_CalculateEncodedSize", "AADHip_EncodePlanCreate",
+    "AADHip_ContextLastError", "AADHip_ContextSignalNextRun", "AADHip_SignalNextRunSupported", "AADHip_ContextSetOption", "AADHip_CalculateEncodedSize", "AADHip_EncodePlanCreate",
     "AADHip_EncodePlanDestroy", "AADHip_EncodePlanRun", "AADHip_DecodePlanCreate", "AADHip_DecodePlanDestroy",
     "AADHip_DecodePlanRun", "AADHip_EncodeBatch", "AADHip_DecodeBatch",
     "AADHip_ReconstructPlanCreate", "AADHip_ReconstructPlanDestroy", "AADHip_ReconstructPlanRun",
@@ -136,6 +136,8 @@ def _declare_hip(lib):
     lib.AADHip_ContextLastError.restype = C.c_char_p
     lib.AADHip_ContextSignalNextRun.argtypes = [vp, vp, vp]
     lib.AADHip_ContextSignalNextRun.restype = C.c_int
+    lib.AADHip_SignalNextRunSupported.argtypes = []
+    lib.AADHip_SignalNextRunSupported.restype = C.c_int32
     lib.AADHip_ContextSetOption.argtypes = [vp, C.c_int32, C.c_int32]
     lib.AADHip_ContextSetOption.restype = C.c_int
     lib.AADHip_CalculateEncodedSize.argtypes = [C.POINTER(AADEncodeParameter), C.c_uint32]

@@ -88,6 +88,7 @@ struct AADHipContext {
   uint64_t trial_capacity;
   /* AADHip_ContextSetOption; the defaults come from the environment ONCE, at creation */
   aad::LaunchSignal signal_next; /* AADHip_ContextSignalNextRun: the events the next plan run records around its work (one-shot) */
+  bool signal_refused;           /* ROC_SYSTEM_SCOPE_SIGNAL=0 at creation: an event on a dispatch packet is never seen by another queue */
   int32_t lane_mapping; /* enum AADHipLaneMapping */
   int32_t trial_lanes;  /* enum AADHipTrialLanes */
   int32_t compare_sequential; /* AAD_HIP_OPTION_COMPARE_ORDER: the -c sums always in the reference's order */
@@ -805,6 +806,7 @@ void AADHipInternal_ContextOptionsFromEnvironment(struct AADHipContext *ctx)
 {
   static const char *const kMappings[] = {"auto", "dense", "quad", "quad-fused", "dense-tiled"};
   static const char *const kTrialLanes[] = {"dual", "single"};
+  ctx->signal_refused = AADHip_SignalNextRunSupported() == 0;
   ctx->lane_mapping = option_from_env("AAD_HIP_MAPPING", kMappings, 5);
   ctx->trial_lanes = option_from_env("AAD_HIP_TRIAL_LANES", kTrialLanes, 2);
   static const char *const kCompareOrders[] = {"auto", "sequential"};
@@ -820,9 +822,26 @@ void AADHipInternal_ContextOptionsFromEnvironment(struct AADHipContext *ctx)
 
 int32_t AADHipInternal_ContextDevice(const struct AADHipContext *ctx) { return ctx->device; }
 
+/* ROC_SYSTEM_SCOPE_SIGNAL=0 makes the ROCm runtime give kernel dispatches DEVICE-scope completion signals.  The events of
+ * AADHip_ContextSignalNextRun ARE the kernel's completion signal (hipExtLaunchKernelGGL's stop event), and a wait on one
+ * from another queue (hipStreamWaitEvent on a second stream: the two-stream pipeline of bench.py / EncodeDecodePipeline)
+ * then never returns - recorded in tools/experiments/README.md ("runtime knobs") and gpurun_out/runtime_knobs.txt of round 3.
+ * The library does not try to work under that setting: it says no. */
+int32_t AADHip_SignalNextRunSupported(void)
+{
+  const char *v = getenv("ROC_SYSTEM_SCOPE_SIGNAL");
+  return (v != nullptr && v[0] == '0' && v[1] == '\0') ? 0 : 1;
+}
+
 AADApiResult AADHip_ContextSignalNextRun(struct AADHipContext *ctx, void *hip_start_event, void *hip_stop_event)
 {
   if (ctx == nullptr) return AAD_APIRESULT_INVALID_ARGUMENT;
+  if (ctx->signal_refused && (hip_start_event != nullptr || hip_stop_event != nullptr)) {
+    snprintf(ctx->last_error, sizeof(ctx->last_error),
+             "AADHip_ContextSignalNextRun: refused, ROC_SYSTEM_SCOPE_SIGNAL=0 (device-scope completion signals: a wait on the "
+             "run's event from another stream would never return); record an event behind the run instead");
+    return AAD_APIRESULT_NG;
+  }
   ctx->signal_next = aad::LaunchSignal{static_cast<hipEvent_t>(hip_start_event), static_cast<hipEvent_t>(hip_stop_event)};
   return AAD_APIRESULT_OK;
 }

@@ -78,6 +78,13 @@ const char *AADHip_ContextLastError(const struct AADHipContext *context);
  * hipStreamWaitEvent as usual.  A run that fails leaves the events unrecorded; the host-memory calls (...Batch, the legacy API)
  * do not look at them. */
 AADApiResult AADHip_ContextSignalNextRun(struct AADHipContext *context, void *hip_start_event, void *hip_stop_event);
+/* NOT available when the process runs with ROC_SYSTEM_SCOPE_SIGNAL=0 (a ROCm runtime setting that gives kernel dispatches
+ * device-scope completion signals): the stop event IS the kernel's completion signal, and another stream's
+ * hipStreamWaitEvent on it would never return.  A context created under that setting refuses the call - AAD_APIRESULT_NG,
+ * AADHip_ContextLastError says why - instead of letting the caller hang; withdrawing (both NULL) always succeeds, and
+ * hipEventRecord behind the run remains the portable way.  AADHip_SignalNextRunSupported: 1, or 0 under that setting
+ * (reads the environment, needs no device). */
+int32_t AADHip_SignalNextRunSupported(void);
 
 /* Launch options of a context.  Defaults: the environment variables AAD_HIP_MAPPING
  * (auto | dense | quad | quad-fused | dense-tiled), AAD_HIP_TRIAL_LANES (dual | single),

@@ -3,6 +3,7 @@
    finished images / PCM - against the oracle;
  - one-shot: the run after the signalled one does not touch the event;
  - empty plans and reconstruction runs (several kernels) record it too;
+ - a context created under ROC_SYSTEM_SCOPE_SIGNAL=0 refuses the call (the one known way to hang a caller);
  - the pipelined step of bench.py (EncodeDecodePipeline) orders its two streams with such events only: many steps, bit-exact."""
 import numpy as np
 import pytest
@@ -113,4 +114,96 @@ def test_pipeline_orders_streams_with_signals_only(torch_mod):
         pipe.close()
     finally:
         e1.close()
+        e2.close()
+
+
+def test_signal_on_reconstruction_run(torch_mod):
+    """AADHip_ReconstructPlanRun is several kernels (encode, decode, compare, finish): `start` is recorded in front of the
+    first, `stop` behind the last (aad_hip_engine.hip, ReconstructPlanRun) - a second stream that waits for `stop` alone
+    reads the finished output and statistics; the nested encode / decode runs neither consume nor re-record the events,
+    and the run after leaves them untouched."""
+    import ctypes as C
+    torch = torch_mod
+    from aad_amd.engine import RECONSTRUCT_DECODED, Engine, HipEvent, _check
+    e = Engine(0, stream=torch.cuda.Stream())
+    other = torch.cuda.Stream()
+    try:
+        streams, samples, ch = 300, 2500, 2
+        param = make_parameter(ch, 4, 1024, 48000, False, 1)
+        host = synth_pcm(streams, samples, ch, seed=77)
+        pcm = torch.from_numpy(host).cuda()
+        size = e.encoded_size(param, samples)
+        stride = -(-size // 16) * 16
+        d = np.zeros(streams, dtype=STREAM_DESC_DTYPE)
+        i = np.arange(streams, dtype=np.uint64)
+        d["pcm_offset"], d["data_offset"], d["data_size"], d["num_samples"] = i * np.uint64(samples * ch), i * np.uint64(stride), stride, samples
+        plan = C.c_void_p()
+        _check("AADHip_ReconstructPlanCreate", e.lib.AADHip_ReconstructPlanCreate(e._ctx, C.byref(param), streams, d.ctypes.data, C.byref(plan)))
+        try:
+            images = torch.empty((streams, stride), dtype=torch.uint8, device="cuda")
+            out = torch.zeros_like(pcm)
+            stats = torch.zeros((streams, 3), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            start, stop = HipEvent(timing=True), HipEvent(timing=True)
+            e.signal_next(stop, start=start)
+            _check("AADHip_ReconstructPlanRun", e.lib.AADHip_ReconstructPlanRun(plan, pcm.data_ptr(), images.data_ptr(), out.data_ptr(),
+                                                                                RECONSTRUCT_DECODED, stats.data_ptr()))
+            stop.wait_on(other)
+            with torch.cuda.stream(other):
+                out_copy, stats_copy = out.clone(), stats.clone()  # ordered behind the run by `stop` alone
+            other.synchronize()
+            first = start.elapsed_ms(stop)
+            assert 0.0 < first < 1000.0
+            for s in (0, 1, streams - 1):
+                img = ob.encode(host[s], 4, 1024, 48000, False, 1)
+                y = ob.decode(img)[0]
+                assert np.array_equal(out_copy[s].cpu().numpy(), y)
+                want = ob.error_stats(host[s], y)
+                got = stats_copy[s].cpu().numpy()
+                assert np.allclose(got, want, rtol=1e-12, atol=0.0), (s, got, want)
+            # the following run carries no events: the pair still holds the first run's interval
+            out.zero_()
+            _check("AADHip_ReconstructPlanRun", e.lib.AADHip_ReconstructPlanRun(plan, pcm.data_ptr(), images.data_ptr(), out.data_ptr(),
+                                                                                RECONSTRUCT_DECODED, stats.data_ptr()))
+            e.stream.synchronize()
+            assert start.elapsed_ms(stop) == first
+            assert torch.equal(out, out_copy)
+        finally:
+            e.lib.AADHip_ReconstructPlanDestroy(plan)
+    finally:
+        e.close()
+
+
+def test_signal_refused_under_device_scope_signals(torch_mod, monkeypatch):
+    """ROC_SYSTEM_SCOPE_SIGNAL=0: a context created under it refuses AADHip_ContextSignalNextRun (NG + a LastError that names the
+    variable) instead of letting a cross-stream wait hang.  The variable is set AFTER this process's HIP runtime came up, so the
+    runtime itself is unaffected - only the library's own check sees it; the hang itself is on record (round 3) and is not re-run."""
+    torch = torch_mod
+    from aad_amd.capi import ApiError
+    from aad_amd.engine import Engine, HipEvent
+    torch.cuda.synchronize()  # the runtime is up
+    monkeypatch.setenv("ROC_SYSTEM_SCOPE_SIGNAL", "0")
+    e = Engine(0, stream=torch.cuda.Stream())
+    try:
+        assert e.lib.AADHip_SignalNextRunSupported() == 0
+        ev = HipEvent()
+        with pytest.raises(ApiError):
+            e.signal_next(ev)
+        assert "ROC_SYSTEM_SCOPE_SIGNAL" in e.last_error()
+        e.signal_next(None)  # withdrawing is always fine
+        # and the context still works without signals
+        param = make_parameter(2, 4, 1024, 48000, False, 0)
+        host = synth_pcm(8, 992, 2, seed=3)
+        img, size = e.encode_uniform(torch.from_numpy(host).cuda(), param)
+        e.stream.synchronize()
+        assert bytes(img[0, :size].cpu().numpy()) == ob.encode(host[0], 4, 1024, 48000, False, 0)
+    finally:
+        e.close()
+    monkeypatch.delenv("ROC_SYSTEM_SCOPE_SIGNAL")
+    e2 = Engine(0, stream=torch.cuda.Stream())
+    try:
+        assert e2.lib.AADHip_SignalNextRunSupported() == 1
+        e2.signal_next(HipEvent())
+        e2.signal_next(None)
+    finally:
         e2.close()

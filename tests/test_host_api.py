@@ -326,3 +326,17 @@ def test_wav_helpers_match_reference_fixtures(lib):
     assert lib.AADWav_ParseHeader(bad.ctypes.data, 8, C.byref(info)) == R.INSUFFICIENT_DATA
     assert lib.AADWav_ParseHeader(None, 64, C.byref(info)) == R.INVALID_ARGUMENT
     assert lib.AADWav_WriteHeader((C.c_uint8 * 44)(), 43, 2, 48000, 10) == R.INSUFFICIENT_BUFFER
+
+
+def test_signal_next_run_support_follows_the_runtime_setting(monkeypatch):
+    """AADHip_SignalNextRunSupported (include/aad_hip.h): 0 exactly when ROC_SYSTEM_SCOPE_SIGNAL=0 - the setting under which a
+    wait on a dispatch-carried event from another stream never returns (round-3 record); no device needed to ask.
+    The refusal itself (AADHip_ContextSignalNextRun -> NG + LastError) needs a context: tests/test_gpu_signal.py."""
+    lib = aad_amd.load_library()
+    monkeypatch.delenv("ROC_SYSTEM_SCOPE_SIGNAL", raising=False)
+    assert lib.AADHip_SignalNextRunSupported() == 1
+    for value, want in (("0", 0), ("1", 1), ("", 1), ("00", 1)):
+        monkeypatch.setenv("ROC_SYSTEM_SCOPE_SIGNAL", value)
+        assert lib.AADHip_SignalNextRunSupported() == want, value
+    # without a context there is nothing to refuse on: the argument check comes first
+    assert lib.AADHip_ContextSignalNextRun(None, None, None) == 1  # AAD_APIRESULT_INVALID_ARGUMENT
