@@ -13,7 +13,8 @@ mean per launch of every counter collected, the kernel-trace duration, and the d
 
 The file carries the SHA-256 over aad_amd/csrc (bench.kernel_source_digest): bench.py refuses to quote
 it once the kernel sources have changed.
-usage: tools/stamp_pmc.py <out.json> <workload>=<dir of pass sub-directories>[:streams:samples_per_channel] ..."""
+usage: tools/stamp_pmc.py [--merge] <out.json> <workload>=<dir of pass sub-directories>[:streams:samples_per_channel] ...
+--merge: keep the workloads <out.json> already holds (they must carry the same kernel-source digest) and add / replace the named ones."""
 import collections
 import csv
 import glob
@@ -81,14 +82,23 @@ def derive(e):
 
 
 def main():
-    out_path = sys.argv[1]
+    argv = sys.argv[1:]
+    merge = bool(argv) and argv[0] == "--merge"
+    if merge:
+        argv = argv[1:]
+    out_path = argv[0]
     sys.path.insert(0, ROOT)
     from bench import kernel_source_digest
     doc = {"kernel_source_sha256": kernel_source_digest(),
            "source": "rocprofv3 --kernel-trace and --pmc passes (FETCH_SIZE and WRITE_SIZE in separate passes, no other trace "
-                     "domain) collected by tools/collect_profiles.sh; means per launch",
+                     "domain) collected by tools/collect_profiles.sh / collect_config_profiles.sh; means per launch",
            "workloads": {}}
-    for spec in sys.argv[2:]:
+    if merge and os.path.exists(out_path):
+        old = json.load(open(out_path))
+        if old.get("kernel_source_sha256") != doc["kernel_source_sha256"]:
+            raise SystemExit("stamp_pmc --merge: %s was taken from other kernel sources" % out_path)
+        doc["workloads"] = old.get("workloads", {})
+    for spec in argv[1:]:
         name, rest = spec.split("=", 1)
         parts = rest.split(":")
         kernels = collect(parts[0])
