@@ -620,7 +620,11 @@ __device__ __forceinline__ void wave_lds_fence()
 __device__ __forceinline__ void store_through(uint64_t address, const u32x4 &v)
 {
 #if AAD_TILED_STORE_SC1
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(address), "v"(v) : "memory");
+  /* s_nop 1 inside the asm: a VMEM store of more than 64 bits needs two wait states before a VALU instruction overwrites its
+   * data registers (gfx940+ ISA hazard).  LLVM's hazard recogniser inserts them for instructions it selected itself, not for
+   * inline asm - and the data registers are dead after this statement, so the register allocator is free to hand them to the
+   * very next VALU result. */
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(address), "v"(v) : "memory");
 #else
   *reinterpret_cast<u32x4 *>(address) = v;
 #endif

@@ -776,10 +776,13 @@ constexpr int kLdsBytesEncoder = kStagedCodes<BITS, CHF, QUAD> ? kLdsCodeStageOf
 /* the instantiations that move their output through ByteRing: dense, mono / stereo, 4- and 2-bit codes (pieces of whole dwords) */
 template <int BITS, int CHF, bool QUAD>
 constexpr bool kRingable = !QUAD && (CHF == 1 || CHF == 2);
+/* The rows' byte rings live in DYNAMIC LDS, one wave's worth per wave of the workgroup (the launch asks for blockDim.x / 64 of
+ * them): a static area for four waves cost the one-wave workgroups of 16 385 .. 65 536-lane batches a resident wave per CU
+ * (72 864 B mono / 54 432 B stereo 4-bit per workgroup instead of 45 216 / 40 608). */
 template <int CHF>
-constexpr int kLdsRingBytes = 4 * (64 / (CHF ? CHF : 1)) * 144; /* four waves of rows */
+constexpr int kLdsRingBytesPerWave = (64 / (CHF ? CHF : 1)) * 144;
 template <int BITS, int CHF, bool QUAD, bool RING>
-constexpr int kLdsBytesEncoderRing = RING ? kLdsCodeStageOff + kLdsRingBytes<CHF> : kLdsBytesEncoder<BITS, CHF, QUAD>;
+constexpr int kLdsBytesEncoderStatic = RING ? kLdsCodeStageOff : kLdsBytesEncoder<BITS, CHF, QUAD>;
 
 /* the lane's bytes of a chunk in memory order (mono: its 8 / 4 code bytes; stereo: its half of the pair's interleaved bytes,
  * as store_chunk_codes / CodeStage::put build them): 4-bit -> d0, d1; 2-bit -> d0 */
@@ -1646,7 +1649,8 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
   static_assert(!QUAD || CHF != 0, "the quad mapping exists for the mono / stereo fast paths");
   static_assert(!DUAL || (QUAD && TRIALS), "the dual mapping is the trial search on the quad mapping");
   static_assert(!RING || kRingable<BITS, CHF, QUAD>, "the byte ring: dense mono / stereo encoders");
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytesEncoderRing<BITS, CHF, QUAD, RING>]; /* dense and quad encoders share the wide table; dense: + code staging or the rows' byte rings */
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytesEncoderStatic<BITS, CHF, QUAD, RING>]; /* dense and quad encoders share the wide table; dense: + code staging */
+  extern __shared__ __attribute__((aligned(16))) char ring_lds[]; /* RING: the rows' byte rings, kLdsRingBytesPerWave per wave (then the occupancy pad, unused) */
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
   stage_tables<BITS, true, kWideStepShift, true>(lds);
   AAD_PHASE_MARK(blockIdx.x == 0 && threadIdx.x == 0);
@@ -1685,7 +1689,7 @@ __global__ void __launch_bounds__(256) encode_streams_kernel(EncodeArgs a)
 
   ByteRing<(CHF ? CHF : 1)> ring;
   if constexpr (RING) {
-    ring.init(lds + kLdsCodeStageOff + (threadIdx.x >> 6) * (kLdsRingBytes<CHF> / 4), (threadIdx.x & 63u) / CHF, out,
+    ring.init(ring_lds + (threadIdx.x >> 6) * kLdsRingBytesPerWave<CHF>, (threadIdx.x & 63u) / CHF, out,
               sd.data_size > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sd.data_size, c);
     /* file header - reference src/aad_encoder.c:190-214 - through the ring, byte by byte (once per stream) */
     const uint32_t encoded = total - a.lead_frames;

@@ -339,11 +339,13 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
     if (quad) launch_encode_mapped<BITS, true, false, false>(a, grid, block, stream);
     else {
       const bool ring = a.ring_ok && a.channels <= 2 && encode_ring_wanted(BITS, a.channels);
-      const unsigned static_lds = ring ? (unsigned)(a.channels == 1 ? aad::kLdsBytesEncoderRing<BITS, 1, false, true> : aad::kLdsBytesEncoderRing<BITS, 2, false, true>)
+      /* the rows' byte rings: dynamic LDS, one wave's worth per wave of the workgroup */
+      const unsigned ring_lds = ring ? (wg / 64u) * (unsigned)(a.channels == 1 ? aad::kLdsRingBytesPerWave<1> : aad::kLdsRingBytesPerWave<2>) : 0u;
+      const unsigned static_lds = ring ? (unsigned)aad::kLdsCodeStageOff + ring_lds
                                   : (a.channels == 1 ? (unsigned)aad::kLdsBytesEncoder<BITS, 1, false>
                                                      : (a.channels == 2 ? (unsigned)aad::kLdsBytesEncoder<BITS, 2, false> : (unsigned)aad::kLdsBytesEncoder<BITS, 0, false>));
       const unsigned pad = wg == 256u ? dense_encode_lds_pad(BITS, lanes, static_lds) : 0u;
-      if (!(ring && launch_encode_ring<BITS, false>(a, grid, block, stream, pad)))
+      if (!(ring && launch_encode_ring<BITS, false>(a, grid, block, stream, ring_lds + pad)))
         launch_encode_mapped<BITS, false, false, false>(a, grid, block, stream, pad);
     }
   }

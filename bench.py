@@ -56,7 +56,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # are the conservative ones).
 SIMDS, CLOCK_GHZ, FULL_RATE_CYCLES, LONE_WAVE_CYCLES_PER_INST = 1024, 2.4, 2.0, 4.0
 MIX_CYCLES = {"encode": 3.80, "decode": 4.00}  # cycles per instruction of the kernels' instruction mix (ubench_rate: encoder_mix, decoder_mix)
-STAMP_FILE = os.path.join(ROOT, "profiles", "r03_pmc_stamp.json")
+STAMP_FILE = os.path.join(ROOT, "profiles", "r04_pmc_stamp.json")
 
 
 def kernel_source_digest():
@@ -525,9 +525,25 @@ def end_to_end(engine, torch, pcm_np, param, reps=20):
                 note="PCIe-inclusive: never the headline `value` (inputs are resident in HBM there)")
 
 
-def config_entry(engine, torch, dist, name, streams, samples, ch, bits, trials, steps, golden):
-    """One of the other BASELINE shapes: kernel time (HIP events), Msamples/s, HBM-roof fraction and
-    the bit-exact flag against the compiled reference's hashes for the same corpus."""
+def config_counters(stamp_key, streams, samples, algorithmic, enc_ms, dec_ms, spb):
+    """Counter evidence of a `configs[]` row from the committed rocprofv3 passes (tools/collect_config_profiles.sh): per kernel the
+    HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE), its ratio to the algorithmic bytes, the VMEM instruction counts and the
+    wave-instructions per sample.  Same stamp rule as the headline: withheld when the kernel sources have changed since."""
+    out = {}
+    for role, kms, per_rec in (("encode", enc_ms, samples), ("decode", dec_ms, min(spb, samples))):
+        st, note = pmc_stamp(stamp_key, role, streams, samples) if stamp_key else (None, "no PMC passes for this row")
+        row = dict({"kernel": (st or {}).get("kernel")}, **traffic_fields(st, note, algorithmic))
+        if st and st.get("SQ_WAVES"):
+            v = valu_fields(st, note, kms, per_rec, role)
+            row["valu"] = {k: v.get(k) for k in ("insts_per_sample", "insts_per_wave", "waves", "frac", "frac_of_full_rate", "lone_wave_issue_frac") if k in v}
+            row["vmem_rd_insts"], row["vmem_wr_insts"] = st.get("SQ_INSTS_VMEM_RD"), st.get("SQ_INSTS_VMEM_WR")
+        out[role] = row
+    return out
+
+
+def config_entry(engine, torch, dist, name, streams, samples, ch, bits, trials, steps, golden, stamp_key=None):
+    """One of the other BASELINE shapes: kernel time (HIP events), Msamples/s, HBM-roof fraction, the counter traffic of the
+    committed PMC passes and the bit-exact flag against the compiled reference's hashes for the same corpus."""
     from aad_amd.capi import make_parameter
     from aad_amd.synth import synth_pcm
     pcm_np = synth_pcm(streams, samples, ch, seed=1234)
@@ -545,9 +561,10 @@ def config_entry(engine, torch, dist, name, streams, samples, ch, bits, trials, 
     return dict(config=name, streams=streams, samples_per_channel=samples, channels=ch, bits=bits, trials=trials,
                 encode_ms=round(m["enc_ms"], 4), decode_ms=round(m["dec_ms"], 4),
                 encode_msps=round(n / m["enc_ms"] / 1e3, 1), decode_msps=round(n / m["dec_ms"] / 1e3, 1),
-                bytes_per_sample=round(bps, 4),
+                bytes_per_sample=round(bps, 4), algorithmic_bytes_per_launch=int(round(n * bps)),
                 encode_frac=round(n * bps / (m["enc_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                 decode_frac=round(n * bps / (m["dec_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                counters=config_counters(stamp_key, streams, samples, int(round(n * bps)), m["enc_ms"], m["dec_ms"], hd.num_samples_per_block),
                 bit_exact_vs_reference_golden=flag)
 
 
@@ -832,12 +849,12 @@ def main():
         }
         line["end_to_end"] = end_to_end(engine, torch, pcm_np, param)
         cfgs = [
-            ("cfg2(ii) 1000 stereo 4-bit streams x 16 blocks", 1000, 992 * 16, 2, 4, 0, 5, "corpus"),
+            ("cfg2(ii) 1000 stereo 4-bit streams x 16 blocks", 1000, 992 * 16, 2, 4, 0, 5, "corpus", "cfg2ii"),
             ("cfg2(iii) 1 stereo 4-bit stream x 1000 blocks (serial worst case: 2 encode recurrences)", 1, 992 * 1000, 2, 4, 0, 2, "corpus"),
             ("cfg2(iii) with trials 2", 1, 992 * 1000, 2, 4, 2, 1, "corpus"),
-            ("cfg4 10000 x 8-channel 3-bit one-block segments", 10000, 292, 8, 3, 0, 10, "eight"),
-            ("cfg4 10000 x 8-channel 2-bit one-block segments", 10000, 444, 8, 2, 0, 10, "eight"),
-            ("cfg5 per-GPU shard: 1250 stereo 4-bit files x 10 blocks", 1250, 9920, 2, 4, 0, 5, "corpus"),
+            ("cfg4 10000 x 8-channel 3-bit one-block segments", 10000, 292, 8, 3, 0, 10, "eight", "cfg4_3bit"),
+            ("cfg4 10000 x 8-channel 2-bit one-block segments", 10000, 444, 8, 2, 0, 10, "eight", "cfg4_2bit"),
+            ("cfg5 per-GPU shard: 1250 stereo 4-bit files x 10 blocks", 1250, 9920, 2, 4, 0, 5, "corpus", "cfg5_shard"),
         ]
         line["configs"] = [config_entry(engine, torch, dist, *c) for c in cfgs]
 

@@ -7,7 +7,7 @@
 # file bench.py quotes, stamped with the SHA-256 of aad_amd/csrc), tools/pmc_db_summary.py and
 # tools/kernel_stats_db.py write the human-readable summaries.  usage: bash tools/collect_profiles.sh [tag]
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
@@ -31,7 +31,11 @@ python3 tools/kernel_stats_db.py $O/sat/kt $O/${TAG}_saturated_kernel_stats_rocp
 python3 tools/pmc_db_summary.py $O/head 2 > $O/${TAG}_pmc_summary_bench.txt
 python3 tools/pmc_db_summary.py $O/sat 1 > $O/${TAG}_saturated_pmc_summary.txt
 python3 tools/stamp_pmc.py $O/${TAG}_pmc_stamp.json headline=$O/head:1000:992 saturated=$O/sat:262144:992
-cp $O/${TAG}_pmc_stamp.json profiles/r03_pmc_stamp.json   # so that the bench line below quotes THIS measurement
+cp $O/${TAG}_pmc_stamp.json profiles/${TAG}_pmc_stamp.json   # so that the bench line below quotes THIS measurement
+# the BASELINE shapes of the line's configs[] rows (cfg4's any-channel kernels, cfg2(ii), cfg5's shard), merged into the same stamp file
+bash tools/collect_config_profiles.sh ${TAG} > $O/config_passes.log 2>&1 || { tail -20 $O/config_passes.log; exit 1; }
+cp profiles/${TAG}_pmc_stamp.json $O/${TAG}_pmc_stamp.json
+cd $R
 # every kernel of the full line (trials 2 = the dual trial-search encoder, the other BASELINE shapes)
 rocprofv3 --kernel-trace --stats -d $O/kt_full -- python3 bench.py --no-saturated --no-cpu-baseline > $O/kt_full.log 2>&1
 python3 tools/kernel_stats_db.py $O/kt_full $O/${TAG}_bench_full_kernel_stats_rocprofv3.csv | head -14
