@@ -261,13 +261,30 @@ bool launch_encode_ring(const aad::EncodeArgs &a, dim3 grid, dim3 block, hipStre
  * every mono encoder and the stereo 4-bit one - their writes fall from 1.3-2.1x to 1.00-1.06x of the code bytes and the kernels
  * get 3-8 % faster; stereo 3- and 2-bit - no: they are VALU-saturated (95 % active), wrote only 1.18x in total before, and the
  * ring's extra ~1 VALU instruction per sample costs them 3-7 % of their time.  AAD_HIP_ENCODE_RING (read at every launch: the
- * tests flip it) = 0: never (A/B measurements), = 2: every geometry that can. */
-bool encode_ring_wanted(uint32_t bits, uint32_t channels)
+ * tests flip it) = 0: never (A/B measurements), = 2: every geometry that can.
+ * Round 4: only in four-wave workgroups.  Batches of 16 385 .. 65 536 lanes run one-wave workgroups (a wave per SIMD, as many
+ * CUs as possible); there the ring is 1-4 % SLOWER than the plain stores (same-box A/B, profiles/r04_encoder_ring_midsize.txt:
+ * mono 40 000 streams 0.1835 vs 0.1811 ms, stereo 4-bit 28 000 streams 0.1044 vs 0.1003 ms) - a launch that leaves SIMDs idle
+ * gains nothing from fewer write sectors and pays the ring's instructions on its critical path. */
+bool encode_ring_wanted(uint32_t bits, uint32_t channels, unsigned workgroup)
 {
   const char *e = getenv("AAD_HIP_ENCODE_RING");
   if (e != nullptr && e[0] == '0') return false;
   if (e != nullptr && e[0] == '2') return true;
-  return channels == 1 || bits == 4;
+  return workgroup == 256u && (channels == 1 || bits == 4);
+}
+
+/* One-wave workgroups (pick_workgroup: up to 65 536 lanes) only while ALL of them can be resident at once: a dense mono encoder
+ * holds 45-52 KB of LDS per workgroup (wide table + code staging or ring rows), so a CU takes three of them and its fourth SIMD
+ * stays empty - from 49 153 lanes (769 waves) on the launch ran in two rounds (mono 4-bit, 64 000 one-block streams: 0.35-0.41 ms
+ * against 0.19 ms for 48 000, profiles/r04_encoder_ring_midsize.txt).  Four-wave workgroups share one table: two per CU. */
+unsigned dense_encode_workgroup(uint64_t lanes, unsigned lds_one_wave)
+{
+  const unsigned wg = pick_workgroup(lanes);
+  if (wg != 64u) return wg;
+  const uint64_t waves = (lanes + 63u) / 64u;
+  const uint64_t resident = 256ull * ((160u << 10) / ((lds_one_wave + 1023u) & ~1023u)); /* CUs x workgroups whose LDS fits */
+  return waves > resident ? 256u : 64u;
 }
 
 template <int BITS, bool QUAD, bool TRIALS, bool DUAL>
@@ -329,7 +346,10 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
   /* dual: eight lanes per recurrence put a wave on twice as many CUs as the trial-free launch; two waves
    * per workgroup (two SIMDs of one CU) keep a small batch on half the chip, so that a decode launched
    * beside it finds free CUs (bench.py's pipelined step with trials 2: 158 -> see DESIGN.md) */
-  const unsigned wg = dual && threads <= 64ull * 1024ull ? 128u : pick_workgroup(threads);
+  unsigned wg = dual && threads <= 64ull * 1024ull ? 128u : pick_workgroup(threads);
+  if (!quad && !a.trials)
+    wg = dense_encode_workgroup(lanes, a.channels == 1 ? (unsigned)aad::kLdsBytesEncoder<BITS, 1, false>
+                                       : (a.channels == 2 ? (unsigned)aad::kLdsBytesEncoder<BITS, 2, false> : (unsigned)aad::kLdsBytesEncoder<BITS, 0, false>));
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
   if (a.trials) {
     if (dual) launch_encode_mapped<BITS, true, true, true>(a, grid, block, stream);
@@ -338,7 +358,7 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
   } else {
     if (quad) launch_encode_mapped<BITS, true, false, false>(a, grid, block, stream);
     else {
-      const bool ring = a.ring_ok && a.channels <= 2 && encode_ring_wanted(BITS, a.channels);
+      const bool ring = a.ring_ok && a.channels <= 2 && encode_ring_wanted(BITS, a.channels, wg);
       /* the rows' byte rings: dynamic LDS, one wave's worth per wave of the workgroup */
       const unsigned ring_lds = ring ? (wg / 64u) * (unsigned)(a.channels == 1 ? aad::kLdsRingBytesPerWave<1> : aad::kLdsRingBytesPerWave<2>) : 0u;
       const unsigned static_lds = ring ? (unsigned)aad::kLdsCodeStageOff + ring_lds
