@@ -36,8 +36,8 @@
  * takes about `blocks of the longest file` x 64 us (x3 with the default trial search) however many
  * files it holds - the blocks of a file are chained - so the more long files share a wave the
  * better; for -e and -d the library cuts the wave into tiles that fit its pinned staging blocks by
- * itself.  The reconstruction modes (-r / -g / -c) are staged whole by the library, so their waves
- * stop at 256 MB of input.
+ * itself; the reconstruction modes (-r / -g / -c) keep a whole wave on the device (encode, decode and
+ * the statistics of all its files in one run) and stage it through the same pinned blocks in chunks.
  *
  * Output names are OUTDIR/<stem><ext>; two inputs with the same stem would overwrite each other,
  * so that is refused up front.  Every output is byte-identical to what the reference CLI writes
@@ -59,9 +59,6 @@
 #include "../../include/aad_wav.h"
 
 #define MAX_DEVICES 16
-/* The reconstruction modes (-r / -g / -c) go through AADHip_ReconstructBatch, the one host-memory entry point the library
- * does NOT cut into tiles: the whole call is staged in one pinned and one device block.  Their waves are kept small here. */
-#define RECONSTRUCT_WAVE_BYTES (256ull << 20)
 #define WAVE_BYTES_DEFAULT (64ull << 30) /* bytes a wave of one device slot spans, max(inputs, outputs) ($AAD_BATCH_WAVE_BYTES overrides: tests) */
 #define WAVE_FILES 8192
 #define QUEUE_DEPTH 2
@@ -369,8 +366,9 @@ static void *reader_main(void *arg)
     /* a wave is sized by what it holds in memory at once: its inputs are mapped, its outputs are
      * allocated - a quarter of the input for -e, up to four times the input for -d */
     const uint64_t weight = s->opt->mode == 'd' ? 4 : 1;
-    const int reconstruct = s->opt->mode == 'r' || s->opt->mode == 'g' || s->opt->mode == 'c';
-    const uint64_t wave_bytes = reconstruct && s->opt->wave_bytes > RECONSTRUCT_WAVE_BYTES ? RECONSTRUCT_WAVE_BYTES : s->opt->wave_bytes;
+    /* -r / -g / -c take the same waves as -e / -d: AADHip_ReconstructBatch stages its PCM through the pinned blocks in chunks
+     * and keeps only device memory for the whole wave (round 4; before that the call was staged whole and waves were capped at 256 MB) */
+    const uint64_t wave_bytes = s->opt->wave_bytes;
     while (i < s->nfiles && (i == w.first || (bytes + weight * s->files[i]->disk_size <= wave_bytes && i - w.first < WAVE_FILES))) {
       bytes += weight * s->files[i]->disk_size;
       if (!load_file(s->opt, s->files[i])) w.failed = 1;

@@ -75,6 +75,9 @@ struct AADHipContext {
   hipStream_t up_stream, down_stream;
   hipEvent_t uploaded[2], computed[2];
   bool have_events, have_pipeline;
+  /* device blocks of the host-memory reconstruction (grow-only): the wave's PCM, its output + statistics */
+  void *d_rc_in, *d_rc_out;
+  size_t rc_in_capacity, rc_out_capacity;
   /* device-only scratch of the reconstruction modes (the .aad images never leave HBM) */
   void *d_scratch;
   size_t scratch_capacity;
@@ -752,6 +755,8 @@ AADApiResult AADHip_ContextCreate(int32_t device_index, void *hip_stream, struct
   ctx->have_pipeline = false;
   ctx->d_scratch = nullptr;
   ctx->scratch_capacity = 0;
+  ctx->d_rc_in = ctx->d_rc_out = nullptr;
+  ctx->rc_in_capacity = ctx->rc_out_capacity = 0;
   ctx->d_residual = nullptr;
   ctx->residual_capacity = 0;
   ctx->d_trial = nullptr;
@@ -805,6 +810,8 @@ void AADHip_ContextDestroy(struct AADHipContext *ctx)
         (void)hipStreamDestroy(ctx->down_stream);
       }
       if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+      if (ctx->d_rc_in) (void)hipFree(ctx->d_rc_in);
+      if (ctx->d_rc_out) (void)hipFree(ctx->d_rc_out);
       if (ctx->d_residual) (void)hipFree(ctx->d_residual);
       if (ctx->d_trial) (void)hipFree(ctx->d_trial);
       if (ctx->d_state) (void)hipFree(ctx->d_state);
@@ -1880,6 +1887,182 @@ AADApiResult AADHip_ReconstructPlanRun(struct AADHipReconstructPlan *plan, const
   return done(hip_ok(ctx, hipGetLastError(), "compare launch") ? AAD_APIRESULT_OK : AAD_APIRESULT_NG);
 }
 
+/*
+ * Host-memory reconstruction.  The COMPUTE stays whole - every stream of a wave is encoded, decoded and compared by one
+ * AADHip_ReconstructPlanRun over device-resident buffers, so that the encoder's block chains of all streams run side by side and
+ * the statistics are summed per stream in the reference's order whatever the batch size - and only the STAGING is cut: the PCM goes
+ * up and the output comes down through the context's two pinned blocks in chunks (the tile budget of the other host-memory entry
+ * points: 16 MiB, or AAD_HIP_OPTION_TILE_KBYTES), chunk k + 1 being filled / chunk k - 1 being scattered by the host while chunk
+ * k is on the bus.  Pinned memory is bounded by the chunk size; device memory holds 2 x PCM + images of a WAVE of whole streams,
+ * and a batch that does not fit the device's free memory (288 GB on MI355X: ~60 G channel-samples) goes as several waves of
+ * consecutive streams.  A forced tile size also forces small waves (64 tiles' worth), so that the tests walk every path.
+ */
+namespace {
+
+struct ReconstructWave {
+  uint32_t first, count;
+};
+
+/* device bytes a stream occupies in a wave: PCM in + PCM out (rows padded to 16 bytes), its image (padded to 16), its statistics */
+uint64_t reconstruct_footprint(uint64_t samples, uint32_t ch, uint64_t image)
+{
+  return 2 * round_up(samples * ch, 8) * sizeof(int16_t) + round_up(image, 16) + sizeof(AADHipErrorStats);
+}
+
+bool device_block_reserve(AADHipContext *ctx, void **block, size_t *capacity, size_t bytes, const char *what)
+{
+  if (*capacity >= bytes) return true;
+  if (*block) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(*block);
+  }
+  *block = nullptr;
+  *capacity = 0;
+  const size_t want = bytes + bytes / 8 + 4096; /* some slack, so that a slightly larger next wave does not reallocate */
+  if (hipMalloc(block, want) == hipSuccess) {
+    *capacity = want;
+    return true;
+  }
+  (void)hipGetLastError();
+  *block = nullptr;
+  if (!hip_ok(ctx, hipMalloc(block, bytes), what)) {
+    *block = nullptr;
+    return false;
+  }
+  *capacity = bytes;
+  return true;
+}
+
+/* one wave: streams [first, first + count) of the batch, device-resident compute, chunked staging */
+AADApiResult reconstruct_wave(AADHipContext *ctx, const struct AADEncodeParameter *parameter, uint32_t count,
+                              const int16_t *const *pcm, const uint32_t *num_samples, int32_t output_kind,
+                              int16_t *const *out_pcm, struct AADHipErrorStats *stats, uint64_t chunk_bytes)
+{
+  const uint32_t ch = parameter->num_channels;
+  std::vector<AADHipStreamDesc> table(count);
+  std::vector<uint64_t> byte_prefix((size_t)count + 1); /* start of every stream's row in the flat PCM block, in bytes */
+  uint64_t pcm_elems = 0, data_bytes = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    const uint64_t size = AADHip_CalculateEncodedSize(parameter, num_samples[i]);
+    table[i].pcm_offset = pcm_elems;
+    table[i].data_offset = data_bytes;
+    table[i].data_size = size;
+    table[i].num_samples = num_samples[i];
+    table[i].reserved = 0;
+    byte_prefix[i] = pcm_elems * sizeof(int16_t);
+    pcm_elems += round_up((uint64_t)num_samples[i] * ch, 8);
+    data_bytes += round_up(size, 16);
+  }
+  byte_prefix[count] = pcm_elems * sizeof(int16_t);
+  AADHipReconstructPlan *plan = nullptr;
+  AADApiResult rc = AADHip_ReconstructPlanCreate(ctx, parameter, count, table.data(), &plan);
+  if (rc != AAD_APIRESULT_OK) return rc;
+  DeviceGuard guard(ctx);
+  /* device: [pcm in] ; [pcm out | statistics] ; [images].  The statistics sit behind the output PCM so that one flat range
+   * comes down. */
+  const size_t pcm_bytes = pcm_elems * sizeof(int16_t), stats_bytes = stats ? sizeof(AADHipErrorStats) * (size_t)count : 0;
+  const size_t stats_off = round_up(pcm_bytes, 64), out_bytes = stats_off + stats_bytes;
+  const size_t chunk = (size_t)round_up(chunk_bytes < 4096 ? 4096 : chunk_bytes, 64);
+  rc = AAD_APIRESULT_NG;
+  do {
+    if (!guard.ok || !ensure_events(ctx)) break;
+    if (!device_block_reserve(ctx, &ctx->d_rc_in, &ctx->rc_in_capacity, pcm_bytes + 64, "hipMalloc reconstruction input") ||
+        !device_block_reserve(ctx, &ctx->d_rc_out, &ctx->rc_out_capacity, out_bytes + 64, "hipMalloc reconstruction output") ||
+        !device_block_reserve(ctx, &ctx->d_scratch, &ctx->scratch_capacity, data_bytes + 64, "hipMalloc image scratch"))
+      break;
+    const size_t stage = pcm_bytes < chunk ? pcm_bytes + 64 : chunk;
+    if (!staging_reserve(ctx, ctx->in[0], stage) || (pcm_bytes > chunk && !staging_reserve(ctx, ctx->in[1], stage))) break;
+    uint8_t *d_in = static_cast<uint8_t *>(ctx->d_rc_in), *d_out = static_cast<uint8_t *>(ctx->d_rc_out);
+
+    /* the rows of streams [a, b) that fall into bytes [lo, hi) of the flat PCM block <-> host block `base` (which holds byte lo at 0) */
+    auto rows = [&](uint32_t a, uint32_t b, uint64_t lo, uint64_t hi, uint8_t *base, bool up) {
+      for (uint32_t i = a; i < b; i++) {
+        const uint64_t r0 = byte_prefix[i], r1 = r0 + (uint64_t)num_samples[i] * ch * sizeof(int16_t);
+        const uint64_t c0 = r0 > lo ? r0 : lo, c1 = r1 < hi ? r1 : hi;
+        if (c1 <= c0) continue;
+        if (up) memcpy(base + (c0 - lo), reinterpret_cast<const uint8_t *>(pcm[i]) + (c0 - r0), (size_t)(c1 - c0));
+        else memcpy(reinterpret_cast<uint8_t *>(out_pcm[i]) + (c0 - r0), base + (c0 - lo), (size_t)(c1 - c0));
+      }
+    };
+    auto span = [&](uint64_t lo, uint64_t hi, uint32_t *a, uint32_t *b) { /* streams whose rows meet [lo, hi) */
+      *a = (uint32_t)(std::upper_bound(byte_prefix.begin(), byte_prefix.end(), lo) - byte_prefix.begin());
+      *a = *a ? *a - 1 : 0;
+      *b = (uint32_t)(std::lower_bound(byte_prefix.begin(), byte_prefix.end(), hi) - byte_prefix.begin());
+      if (*b > count) *b = count;
+    };
+
+    /* ---- up: chunk k is filled while chunk k - 1 is on the bus ---- */
+    bool ok = true;
+    uint32_t k = 0;
+    for (uint64_t lo = 0; lo < pcm_bytes && ok; lo += chunk, k++) {
+      const uint64_t hi = lo + chunk < pcm_bytes ? lo + chunk : pcm_bytes;
+      Staging &st = ctx->in[k & 1];
+      if (k >= 2) ok = hip_ok(ctx, hipEventSynchronize(ctx->chunk_done[k & 1]), "hipEventSynchronize"); /* the block's last copy has left it */
+      if (!ok) break;
+      uint32_t a, b;
+      span(lo, hi, &a, &b);
+      uint8_t *host = static_cast<uint8_t *>(st.host);
+      staged_span(ctx, a, b, byte_prefix, [&](uint32_t x, uint32_t y) { rows(x, y, lo, hi, host, true); });
+      ok = hip_ok(ctx, hipMemcpyAsync(d_in + lo, host, (size_t)(hi - lo), hipMemcpyHostToDevice, ctx->stream), "H2D pcm") &&
+           hip_ok(ctx, hipEventRecord(ctx->chunk_done[k & 1], ctx->stream), "hipEventRecord");
+    }
+    if (!ok) break;
+
+    /* ---- compute: one run over the whole wave ---- */
+    rc = AADHip_ReconstructPlanRun(plan, reinterpret_cast<const int16_t *>(d_in), static_cast<uint8_t *>(ctx->d_scratch),
+                                   reinterpret_cast<int16_t *>(d_out), output_kind,
+                                   stats ? reinterpret_cast<AADHipErrorStats *>(d_out + stats_off) : nullptr);
+    if (rc != AAD_APIRESULT_OK) break;
+    rc = AAD_APIRESULT_NG;
+
+    /* ---- down: [PCM (if wanted) | statistics] as one flat range; chunk k - 1 is scattered while chunk k is on the bus.
+     * Statistics only: nothing but 24 bytes per stream comes back. ---- */
+    const uint64_t down_lo = out_pcm ? 0 : stats_off, down_hi = stats ? out_bytes : (out_pcm ? pcm_bytes : down_lo);
+    if (down_hi > down_lo) {
+      const size_t dstage = (size_t)(down_hi - down_lo) < chunk ? (size_t)(down_hi - down_lo) + 64 : chunk;
+      if (!staging_reserve(ctx, ctx->out[0], dstage) || (down_hi - down_lo > chunk && !staging_reserve(ctx, ctx->out[1], dstage))) break;
+      auto scatter = [&](uint32_t kk, uint64_t lo, uint64_t hi) { /* host block kk & 1 holds bytes [lo, hi) of the output block */
+        uint8_t *host = static_cast<uint8_t *>(ctx->out[kk & 1].host);
+        if (out_pcm && lo < pcm_bytes) {
+          const uint64_t ph = hi < pcm_bytes ? hi : pcm_bytes;
+          uint32_t a, b;
+          span(lo, ph, &a, &b);
+          staged_span(ctx, a, b, byte_prefix, [&](uint32_t x, uint32_t y) { rows(x, y, lo, ph, host, false); });
+        }
+        if (stats && hi > stats_off) {
+          const uint64_t s0 = lo > stats_off ? lo : stats_off;
+          memcpy(reinterpret_cast<uint8_t *>(stats) + (s0 - stats_off), host + (s0 - lo), (size_t)(hi - s0));
+        }
+      };
+      uint64_t prev_lo = 0, prev_hi = 0;
+      bool have_prev = false;
+      k = 0;
+      for (uint64_t lo = down_lo; lo < down_hi && ok; lo += chunk, k++) {
+        const uint64_t hi = lo + chunk < down_hi ? lo + chunk : down_hi;
+        ok = hip_ok(ctx, hipMemcpyAsync(ctx->out[k & 1].host, d_out + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, ctx->stream), "D2H block") &&
+             hip_ok(ctx, hipEventRecord(ctx->chunk_done[k & 1], ctx->stream), "hipEventRecord");
+        if (ok && have_prev) { /* the other block: its copy was queued one round ago */
+          ok = hip_ok(ctx, hipEventSynchronize(ctx->chunk_done[(k - 1) & 1]), "hipEventSynchronize");
+          if (ok) scatter(k - 1, prev_lo, prev_hi);
+        }
+        prev_lo = lo, prev_hi = hi, have_prev = true;
+      }
+      if (ok && have_prev) {
+        ok = hip_ok(ctx, hipEventSynchronize(ctx->chunk_done[(k - 1) & 1]), "hipEventSynchronize");
+        if (ok) scatter(k - 1, prev_lo, prev_hi);
+      }
+      if (!ok) break;
+    }
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
+    rc = AAD_APIRESULT_OK;
+  } while (0);
+  if (rc != AAD_APIRESULT_OK) (void)hipStreamSynchronize(ctx->stream); /* nothing of this call stays in flight */
+  AADHip_ReconstructPlanDestroy(plan);
+  return rc;
+}
+
+} /* namespace */
+
 AADApiResult AADHip_ReconstructBatch(struct AADHipContext *ctx, const struct AADEncodeParameter *parameter,
                                      uint32_t num_streams, const int16_t *const *pcm, const uint32_t *num_samples,
                                      int32_t output_kind, int16_t *const *out_pcm, struct AADHipErrorStats *stats)
@@ -1887,59 +2070,35 @@ AADApiResult AADHip_ReconstructBatch(struct AADHipContext *ctx, const struct AAD
   if (ctx == nullptr || parameter == nullptr || (num_streams != 0 && (pcm == nullptr || num_samples == nullptr)))
     return AAD_APIRESULT_INVALID_ARGUMENT;
   if (num_streams == 0) return AAD_APIRESULT_OK;
-  std::vector<AADHipStreamDesc> table(num_streams);
-  uint64_t pcm_elems = 0, data_bytes = 0;
   const uint32_t ch = parameter->num_channels;
-  for (uint32_t i = 0; i < num_streams; i++) {
+  std::vector<uint64_t> footprint(num_streams);
+  for (uint32_t i = 0; i < num_streams; i++) { /* the whole batch is validated before the first wave runs */
     if (pcm[i] == nullptr || (out_pcm != nullptr && out_pcm[i] == nullptr)) return AAD_APIRESULT_INVALID_ARGUMENT;
     const uint64_t size = AADHip_CalculateEncodedSize(parameter, num_samples[i]);
     if (size == 0) return AAD_APIRESULT_INVALID_FORMAT;
-    table[i].pcm_offset = pcm_elems;
-    table[i].data_offset = data_bytes;
-    table[i].data_size = size;
-    table[i].num_samples = num_samples[i];
-    table[i].reserved = 0;
-    pcm_elems += round_up((uint64_t)num_samples[i] * ch, 8);
-    data_bytes += round_up(size, 16);
+    footprint[i] = reconstruct_footprint(num_samples[i], ch, size);
   }
-  AADHipReconstructPlan *plan = nullptr;
-  AADApiResult rc = AADHip_ReconstructPlanCreate(ctx, parameter, num_streams, table.data(), &plan);
-  if (rc != AAD_APIRESULT_OK) return rc;
-  DeviceGuard guard(ctx);
-  /* input block: pcm ; output block: pcm out | stats ; the images stay in a device-only scratch */
-  const size_t pcm_bytes = pcm_elems * sizeof(int16_t), stats_bytes = stats ? sizeof(AADHipErrorStats) * (size_t)num_streams : 0;
-  const size_t stats_off = round_up(pcm_bytes, 64);
-  rc = AAD_APIRESULT_NG;
-  do {
-    if (!guard.ok) break;
-    if (!staging_reserve(ctx, ctx->in[0], pcm_bytes + 64) || !staging_reserve(ctx, ctx->out[0], stats_off + stats_bytes + 64)) break;
-    if (ctx->scratch_capacity < data_bytes + 64) {
-      if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-      ctx->d_scratch = nullptr;
-      ctx->scratch_capacity = 0;
-      if (!hip_ok(ctx, hipMalloc(&ctx->d_scratch, data_bytes + data_bytes / 4 + 4096), "hipMalloc image scratch")) break;
-      ctx->scratch_capacity = data_bytes + data_bytes / 4 + 4096;
-    }
-    int16_t *hin = static_cast<int16_t *>(ctx->in[0].host);
-    uint8_t *hout = static_cast<uint8_t *>(ctx->out[0].host), *dout = static_cast<uint8_t *>(ctx->out[0].dev);
-    for (uint32_t i = 0; i < num_streams; i++)
-      memcpy(hin + table[i].pcm_offset, pcm[i], (size_t)num_samples[i] * ch * sizeof(int16_t));
-    if (!hip_ok(ctx, hipMemcpyAsync(ctx->in[0].dev, hin, pcm_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D pcm")) break;
-    rc = AADHip_ReconstructPlanRun(plan, (const int16_t *)ctx->in[0].dev, (uint8_t *)ctx->d_scratch, (int16_t *)dout,
-                                   output_kind, stats ? (AADHipErrorStats *)(dout + stats_off) : nullptr);
-    if (rc != AAD_APIRESULT_OK) break;
-    rc = AAD_APIRESULT_NG;
-    /* statistics only: nothing but 24 bytes per stream comes back */
-    const size_t back_off = out_pcm ? 0 : stats_off, back_bytes = (out_pcm ? stats_off : 0) + stats_bytes;
-    if (back_bytes && !hip_ok(ctx, hipMemcpyAsync(hout + back_off, dout + back_off, back_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H block")) break;
-    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) break;
-    if (out_pcm)
-      for (uint32_t i = 0; i < num_streams; i++)
-        memcpy(out_pcm[i], reinterpret_cast<const int16_t *>(hout) + table[i].pcm_offset, (size_t)num_samples[i] * ch * sizeof(int16_t));
-    if (stats) memcpy(stats, hout + stats_off, stats_bytes);
-    rc = AAD_APIRESULT_OK;
-  } while (0);
-  AADHip_ReconstructPlanDestroy(plan);
+  const uint64_t chunk = ctx->tile_bytes > 0 ? (uint64_t)ctx->tile_bytes : kChunkBudget;
+  uint64_t budget;
+  if (ctx->tile_bytes > 0) {
+    budget = (uint64_t)ctx->tile_bytes * 64u; /* a forced tile size: small waves too (tests) */
+  } else {
+    DeviceGuard guard(ctx);
+    size_t free_bytes = 0, total_bytes = 0;
+    if (!guard.ok || !hip_ok(ctx, hipMemGetInfo(&free_bytes, &total_bytes), "hipMemGetInfo")) return AAD_APIRESULT_NG;
+    /* what is free now plus what this context's own grow-only blocks already hold, less a quarter for everybody else */
+    const uint64_t own = ctx->rc_in_capacity + ctx->rc_out_capacity + ctx->scratch_capacity;
+    budget = ((uint64_t)free_bytes + own) / 4 * 3;
+  }
+  AADApiResult rc = AAD_APIRESULT_OK;
+  for (uint32_t first = 0; first < num_streams && rc == AAD_APIRESULT_OK;) {
+    uint32_t n = 0;
+    uint64_t sum = 0;
+    while (first + n < num_streams && (n == 0 || sum + footprint[first + n] <= budget)) sum += footprint[first + n++]; /* a stream alone is always tried */
+    rc = reconstruct_wave(ctx, parameter, n, pcm + first, num_samples + first, output_kind, out_pcm ? out_pcm + first : nullptr,
+                          stats ? stats + first : nullptr, chunk);
+    first += n;
+  }
   return rc;
 }
 

@@ -91,6 +91,40 @@ def test_reconstruct_batch_matches_reference_cli(engine):
             assert _as_tuple(stats2[i]) == _as_tuple(stats[i]) == _as_tuple(only_stats[i])
 
 
+@pytest.mark.parametrize("tile_kbytes", [1, 7, 300])
+def test_reconstruct_batch_in_chunks_and_waves(engine, tile_kbytes):
+    """AADHip_ReconstructBatch stages its PCM through the pinned blocks in chunks of the tile budget and, when the batch does
+    not fit the device, runs it as several waves of whole streams (aad_hip_engine.hip, reconstruct_wave): a forced tile size
+    (AAD_HIP_OPTION_TILE_KBYTES) makes the chunks a few KiB and the waves 64 tiles' worth, so that ragged batches - one-sample
+    streams next to streams longer than a chunk AND longer than a wave, 1 / 2 / 8 channels, trial search, M/S - cross every
+    boundary: chunk edges inside a stream's row, rows inside the padding between streams, the statistics block split over
+    chunks.  Same bytes and the same doubles as the call with everything in one piece; PCM and the printed line == the oracle."""
+    rng = np.random.default_rng(900 + tile_kbytes)
+    for ch, bits, trials, ms, count in ((2, 4, 2, False, 90), (1, 3, 0, False, 400), (8, 2, 0, False, 40), (2, 2, 1, True, 130)):
+        lengths = [int(rng.choice([1, 3, 4, 5, 200, 992, 993, int(rng.integers(1, 5000)), int(rng.integers(5000, 40000))])) for _ in range(count)]
+        lengths[count // 2] = 150000  # longer than any wave at tile_kbytes = 1 (64 KiB): a wave of its own
+        pcms = [synth_pcm(1, n, ch, seed=int(rng.integers(0, 1 << 30)), kind=str(rng.choice(["music", "noise"])))[0] for n in lengths]
+        param = make_parameter(ch, bits, 1024, 48000, ms, trials)
+        engine.set_tile_kbytes(0)
+        rec0, stats0 = engine.reconstruct_host(pcms, param, residual=False)
+        gap0, _ = engine.reconstruct_host(pcms, param, residual=True)
+        engine.set_tile_kbytes(tile_kbytes)
+        try:
+            rec, stats = engine.reconstruct_host(pcms, param, residual=False)
+            gap, stats_g = engine.reconstruct_host(pcms, param, residual=True)
+            only = engine.reconstruct_host(pcms, param, want_pcm=False)[1]
+            no_stats = engine.reconstruct_host(pcms, param, want_stats=False)[0]
+        finally:
+            engine.set_tile_kbytes(0)
+        for i, pcm in enumerate(pcms):
+            assert np.array_equal(rec[i], rec0[i]) and np.array_equal(gap[i], gap0[i]) and np.array_equal(no_stats[i], rec0[i]), (tile_kbytes, ch, bits, i, lengths[i])
+            assert _as_tuple(stats[i]) == _as_tuple(stats0[i]) == _as_tuple(stats_g[i]) == _as_tuple(only[i]), (tile_kbytes, ch, bits, i, lengths[i])
+        for i in list(range(0, count, 9)) + [count // 2]:
+            want = ob.decode(ob.encode(pcms[i], bits, 1024, 48000, ms, trials))[0]
+            assert np.array_equal(rec[i], want) and np.array_equal(gap[i], ob.residual(pcms[i], want)), (tile_kbytes, ch, bits, i, lengths[i])
+            assert ob.stats_line(_as_tuple(stats[i])) == ob.stats_line(ob.error_stats(pcms[i], want))
+
+
 @pytest.mark.parametrize("streams,samples,ch,bits", [(1000, 992, 2, 4), (3, 70001, 1, 3), (64, 4000, 8, 2)])
 def test_reconstruct_device_resident_vs_oracle(engine, streams, samples, ch, bits):
     """device-resident form (AADHip_ReconstructPlanRun): nothing but the statistics needs to leave
@@ -170,9 +204,11 @@ def test_aad_batch_cli_reconstruction_modes(tmp_path):
             files = ["-l", str(listfile), wavs[names[0]]]
         else:
             files = [wavs[n] for n in use]
-        subprocess.run([CLI, "-r"] + opts + ["-o", str(rdir)] + files, check=True)
-        subprocess.run([CLI, "--gap"] + opts + ["--output-dir", str(gdir)] + files, check=True)
-        out = subprocess.run([CLI, "-c"] + opts + files, check=True, capture_output=True, text=True).stdout
+        # the third parameter set with a forced tile size: the library's chunked staging and several device waves under the CLI
+        env = dict(os.environ, AAD_HIP_TILE_KBYTES="3") if bits == 2 else None
+        subprocess.run([CLI, "-r"] + opts + ["-o", str(rdir)] + files, check=True, env=env)
+        subprocess.run([CLI, "--gap"] + opts + ["--output-dir", str(gdir)] + files, check=True, env=env)
+        out = subprocess.run([CLI, "-c"] + opts + files, check=True, capture_output=True, text=True, env=env).stdout
         lines = dict(l.split("\t", 1) for l in out.splitlines(keepends=True))
         assert len(lines) == len(use)
         for n in use:
