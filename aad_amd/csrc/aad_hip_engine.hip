@@ -394,9 +394,22 @@ unsigned dense_decode_lds_pad(uint64_t lanes, uint32_t channels, uint32_t bits)
   return gains && lanes >= 65536 ? kTarget - (unsigned)aad::kLdsBytesDenseDec : 0u;
 }
 
-template <int BITS, bool QUAD>
-void launch_decode_mapped(const aad::DecodeArgs &a, dim3 grid, dim3 block, hipStream_t stream)
+/* The dense stereo decoder's streamed (non-temporal) PCM stores: AAD_HIP_DECODE_NT_MIN (lanes, read once) is the batch size
+ * from which they are taken where the layout allows (DecodeArgs::stream_stores); measurement aid, never changes a byte. */
+uint64_t decode_nt_min_lanes()
 {
+  static const uint64_t v = [] {
+    const char *e = getenv("AAD_HIP_DECODE_NT_MIN");
+    return e ? (uint64_t)atoll(e) : 0ull;
+  }();
+  return v;
+}
+
+template <int BITS, bool QUAD>
+void launch_decode_mapped(const aad::DecodeArgs &args, dim3 grid, dim3 block, hipStream_t stream)
+{
+  aad::DecodeArgs a = args;
+  if (a.total_blocks * a.channels < decode_nt_min_lanes()) a.stream_stores = 0;
   const unsigned lds_pad = !QUAD && block.x == 256u ? dense_decode_lds_pad(a.total_blocks * a.channels, a.channels, a.bits) : 0u;
   if (a.channels == 1)
     AAD_LAUNCH((aad::decode_blocks_kernel<BITS, 1, false, QUAD>), grid, block, lds_pad, stream, a);
