@@ -376,8 +376,13 @@ int aado_encode_stream(const int16_t *pcm, uint32_t num_samples, uint32_t channe
 
 /* ---- decoder ------------------------------------------------------------------------- */
 
-int aado_decode_block(const AadoHeader *hd, const uint8_t *block, size_t size,
-                      int16_t *pcm, uint32_t want_frames, uint32_t *got_frames)
+/* `size`: what the caller declares as the block's bytes (the header check of :351-353); `readable`: bytes from `block` on that
+ * may be READ.  The reference's code walk has no bound of its own (asserts only, :399-400): when the header's
+ * samples_per_block asks for more codes than block_size holds (the header checks, :173-225, relate neither to the other) it
+ * reads on into the bytes that follow - inside AADDecoder_DecodeWhole that is the rest of the file.  Beyond `readable`
+ * (where the reference would leave its buffer) bytes read as zero. */
+static int decode_block_readable(const AadoHeader *hd, const uint8_t *block, size_t size, size_t readable,
+                                 int16_t *pcm, uint32_t want_frames, uint32_t *got_frames)
 {
   if (!hd || !block || !pcm || !got_frames) return AADO_INVALID_ARGUMENT;
   const uint32_t ch = hd->num_channels, bits = hd->bits_per_sample;
@@ -403,7 +408,7 @@ int aado_decode_block(const AadoHeader *hd, const uint8_t *block, size_t size,
     for (uint32_t k = 0; k < AADO_TAPS && k < want_frames; k++) /* :386-391 */
       pcm[(size_t)k * ch + c] = (int16_t)lanes[c].h[AADO_TAPS - 1 - k];
   }
-  const uint8_t *end = block + size;
+  const uint8_t *end = block + readable;
   for (uint32_t s = AADO_TAPS; s < n; s += u.unit_samples) { /* :394-455 */
     for (uint32_t c = 0; c < ch; c++) {
       uint32_t acc = 0;
@@ -427,6 +432,12 @@ int aado_decode_block(const AadoHeader *hd, const uint8_t *block, size_t size,
   return AADO_OK;
 }
 
+int aado_decode_block(const AadoHeader *hd, const uint8_t *block, size_t size,
+                      int16_t *pcm, uint32_t want_frames, uint32_t *got_frames)
+{
+  return decode_block_readable(hd, block, size, size, pcm, want_frames, got_frames);
+}
+
 int aado_decode_stream(const uint8_t *data, size_t size, uint32_t max_channels,
                        int16_t *pcm, uint32_t pcm_frames, AadoHeader *hd_out)
 {
@@ -442,8 +453,8 @@ int aado_decode_stream(const uint8_t *data, size_t size, uint32_t max_channels,
   while (progress < hd.num_samples && off < size) { /* reference src/aad_decoder.c:514-534 */
     size_t take = size - off < hd.block_size ? size - off : hd.block_size;
     uint32_t got = 0;
-    rc = aado_decode_block(&hd, data + off, take, pcm + (size_t)progress * hd.num_channels,
-                           pcm_frames - progress, &got);
+    rc = decode_block_readable(&hd, data + off, take, size - off, pcm + (size_t)progress * hd.num_channels,
+                               pcm_frames - progress, &got);
     if (rc != AADO_OK) return rc;
     off += take;
     progress += got;

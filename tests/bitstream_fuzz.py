@@ -225,7 +225,47 @@ def golden_cases():
 
 def case_of_record(rec):
     """rebuild the image a golden record was made from (and check that the generator has not drifted)"""
-    case = make_case(rec["name"]) if rec["name"].startswith("c") else make_case(rec["name"], channels=rec["channels"])
+    if rec["name"].startswith("g"):
+        case = make_geometry_case(rec["name"])
+    else:
+        case = make_case(rec["name"]) if rec["name"].startswith("c") else make_case(rec["name"], channels=rec["channels"])
     if hashlib.sha256(case["image"]).hexdigest() != rec["image_sha256"]:
         raise AssertionError("bitstream_fuzz.make_case(%r) no longer produces the image the golden was made from" % rec["name"])
     return case
+
+
+def make_geometry_case(name, max_channels=2):
+    """A file header whose block_size and samples_per_block do NOT belong together.  The reference checks neither against the other
+    (src/aad_decoder.c:173-225: block_size > 18 x channels, samples_per_block > 0, that is all): its block walk advances by
+    block_size (:514-534) while a block's decode consumes what samples_per_block asks for (:396-451) - fewer bytes than the block
+    holds, or MORE (reading on into the following blocks' bytes), and fewer than four samples per block still emits the header's
+    stored samples (:386-391).  Defined as long as every read stays inside the file (the reference does not bound-check its reads in
+    release builds): the image carries a tail of bytes behind its last block, long enough for the farthest read; the block walk
+    never reaches it (it stops at num_samples), only overflowing code reads do."""
+    src = Bytes("aad-geometry-fuzz/" + name)
+    ch = src.choice([1, 2, 2]) if max_channels <= 2 else 1 + src.below(max_channels)
+    b = src.choice([4, 3, 2])
+    ms = bool(ch == 2 and src.below(4) == 0)
+    unit_samples = {4: 2, 3: 8, 2: 4}[b]
+    unit_bytes = {4: 1, 3: 3, 2: 1}[b] * ch
+    block_size = 18 * ch + 1 + src.below(src.choice([20, 200, 1200]))
+    fits = 4 + (block_size - 18 * ch) // unit_bytes * unit_samples  # samples a block of this size can hold
+    spb = src.choice([1 + src.below(8), max(1, fits - src.below(min(fits, 40))), fits, fits + 1 + src.below(3 * fits + 50), 1 + src.below(3000)])
+    blocks = 1 + src.below(4)
+    # the last block: as many samples as stay inside its own bytes
+    last_cap = min(spb, fits)
+    last = 1 + src.below(last_cap)
+    num_samples = (blocks - 1) * spb + last
+    def needed(n):  # bytes a block's decode of n samples touches, from the block's first byte
+        return 18 * ch + -(-max(n - 4, 0) // unit_samples) * unit_bytes
+    reach = max([k * block_size + needed(spb) for k in range(blocks - 1)] + [(blocks - 1) * block_size + needed(last)])
+    body = hashlib.shake_256(src.take(16)).digest(max(blocks * block_size, reach))
+    image = bytearray(file_header(ch, num_samples, 48000, b, block_size, spb, ms)) + bytearray(body)
+    hk = src.choice(HEADER_KINDS)
+    for k in range(blocks):  # proper channel headers at the head of every block (index field <= 4087)
+        for c in range(ch):
+            o = HEADER_BYTES + k * block_size + 18 * c
+            if o + 18 <= len(image):
+                image[o:o + 18] = _channel_header(src, hk)
+    return {"name": name, "channels": ch, "bits": b, "ms": ms, "block_size": block_size, "spb": spb, "fits": fits,
+            "num_samples": num_samples, "blocks": blocks, "image": bytes(image)}

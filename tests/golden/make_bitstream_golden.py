@@ -12,6 +12,9 @@ oracle/_ref/libaadref.so's AADDecoder_DecodeWhole and records, per case, the SHA
   m0000..  3-8 channels: the reference cannot (AAD_MAX_NUM_CHANNELS = 2, src/aad.h:13); every
            channel is decoded as the equivalent mono image (`channel_as_mono_image`, the rule of
            SURVEY.md section 8c) and the columns are put side by side
+  g0000..  1-2 channels, file headers whose block_size and samples_per_block do not belong together
+           (`make_geometry_case`): the reference checks neither against the other, walks blocks by
+           block_size and reads codes by samples_per_block - on into the following blocks' bytes if need be
 
 Output: tests/golden/bitstream_fuzz.json.  Runs only in the build container (needs oracle/_ref);
 nothing of the reference's source is copied - only hashes of what it computed.
@@ -34,6 +37,7 @@ from helpers import sha256  # noqa: E402
 
 STEREO_CASES = 600
 WIDE_CASES = 200
+GEOMETRY_CASES = 300
 
 
 def reference_decode(ref, case):
@@ -56,6 +60,15 @@ def main():
             rec["image_sha256"] = sha256(case["image"])
             rec["decoded_sha256"] = bf.pcm_hash(pcm)
             cases.append(rec)
+    for name in bf.case_names(GEOMETRY_CASES, "g"):
+        case = bf.make_geometry_case(name)
+        pcm = ref.decode(case["image"])[0]
+        assert pcm.shape == (case["num_samples"], case["channels"])
+        rec = {k: case[k] for k in ("name", "channels", "bits", "ms", "block_size", "spb", "num_samples", "fits", "blocks")}
+        rec["header_kind"], rec["body_kind"] = "geometry", "random"
+        rec["image_sha256"] = sha256(case["image"])
+        rec["decoded_sha256"] = bf.pcm_hash(pcm)
+        cases.append(rec)
     out = {"generator": "tests/golden/make_bitstream_golden.py", "source": "oracle/_ref/libaadref.so (AADDecoder_DecodeWhole)",
            "cases": cases}
     path = os.path.join(HERE, "bitstream_fuzz.json")

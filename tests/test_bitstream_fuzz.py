@@ -9,6 +9,11 @@ M/S, 1-3 blocks with a ragged last one.
     every GPU decode path;
   * `ref`-marked: fresh seeds against the compiled reference itself (build container only).
 
+Round 4, second family: file headers whose block_size and samples_per_block do not belong together (the reference's header
+checks relate neither to the other, src/aad_decoder.c:173-225): blocks are walked by block_size, codes read by
+samples_per_block - on into the following blocks' bytes when a block is too small for its samples (found there: the oracle
+read zeros past the block's end; the reference reads the file's next bytes).
+
 Found by this file's first run: the oracle (and the three GPU decoders) clamped a block header's
 step index to 4080; the reference takes the field as it is (:365-366), so 4081..4087 - same table
 slot, 255 - continue the index walk from the unclamped value.
@@ -23,12 +28,14 @@ GOLDEN = bf.golden_cases()
 
 
 def test_golden_covers_the_input_classes():
-    keys = {(r["header_kind"], r["body_kind"]) for r in GOLDEN}
+    keys = {(r["header_kind"], r["body_kind"]) for r in GOLDEN if r["header_kind"] != "geometry"}
     assert len(keys) == len(bf.HEADER_KINDS) * len(bf.BODY_KINDS)
+    geo = [r for r in GOLDEN if r["header_kind"] == "geometry"]
+    assert len(geo) == 300 and sum(r["spb"] > r["fits"] for r in geo) > 60 and sum(r["spb"] < 4 for r in geo) > 10
     assert {r["bits"] for r in GOLDEN} == {2, 3, 4}
     assert {r["channels"] for r in GOLDEN} == set(range(1, 9))
     assert any(r["ms"] for r in GOLDEN)
-    assert len(GOLDEN) == 800
+    assert len(GOLDEN) == 1100
 
 
 @pytest.mark.parametrize("part", range(8))
@@ -42,6 +49,7 @@ def test_crafted_streams_reach_the_corners():
     """the generator does what its docstring says: both rails, both index clamps, wrapping predictions"""
     lo = hi = rails = wraps = top = 0
     for rec in GOLDEN[:300]:
+        assert rec["header_kind"] != "geometry"
         case = bf.case_of_record(rec)
         img, ch = case["image"], case["channels"]
         pcm = bf.oracle_decode(img)
@@ -76,6 +84,10 @@ def test_oracle_matches_compiled_reference_on_fresh_seeds(part):
     ref = aad_amd.LegacyCodec(aad_amd.load_library(ob.REF_SO, hip=False))
     for name in bf.case_names(400, "r%d-" % part):
         case = bf.make_case(name)
+        want, _ = ref.decode(case["image"])
+        assert np.array_equal(bf.oracle_decode(case["image"]), want), name
+    for name in bf.case_names(400, "g%d-" % part):  # inconsistent block_size / samples_per_block
+        case = bf.make_geometry_case(name)
         want, _ = ref.decode(case["image"])
         assert np.array_equal(bf.oracle_decode(case["image"]), want), name
     for i, name in enumerate(bf.case_names(60, "w%d-" % part)):

@@ -5,7 +5,8 @@ alternations, noise), 1-8 channels, 2/3/4 bits, M/S, 1-3 blocks with a ragged la
 
 The reference defines a result for any such bytes (src/aad_decoder.c:364-391 header reload, :376 the shift,
 :396-451 the code walk).  Pins:
-  * tests/golden/bitstream_fuzz.json - 800 images' decode hashes from the COMPILED reference
+  * tests/golden/bitstream_fuzz.json - 1100 images' decode hashes from the COMPILED reference (800 crafted block contents, 300 file
+    headers whose block_size and samples_per_block do not belong together: blocks walked by one, codes read by the other)
     (make_bitstream_golden.py); tests/test_bitstream_fuzz.py holds the oracle to the same hashes on the CPU;
   * the oracle, for the same-format batches built here (checked against the reference in the build container by
     test_bitstream_fuzz.py::test_oracle_matches_compiled_reference_on_fresh_seeds).
@@ -184,6 +185,30 @@ def test_legacy_api_on_crafted_images():
             assert bf.pcm_hash(np.concatenate(parts)) == rec["decoded_sha256"], ("DecodeBlock", rec["name"])
         done += 1
     assert done == 200
+    geometry = [rec for rec in GOLDEN if rec["header_kind"] == "geometry"][::4]
+    for rec in geometry:  # inconsistent block_size / samples_per_block: AADDecoder_DecodeWhole walks by one and reads by the other
+        pcm, _ = codec.decode(bf.case_of_record(rec)["image"])
+        assert bf.pcm_hash(pcm) == rec["decoded_sha256"], ("DecodeWhole, geometry", rec["name"], rec["block_size"], rec["spb"], rec["fits"])
+    assert len(geometry) == 75
+
+
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_inconsistent_geometry_up_to_eight_channels(engine, mapping):
+    """block_size and samples_per_block that do not belong together, 1-8 channels (the reference-pinned 1-2 channel cases are in the
+    golden set above; wider ones against the oracle, which the build container holds to the reference on this input class)"""
+    engine.set_mapping(mapping)
+    try:
+        for tile in (0, 1):
+            engine.set_tile_kbytes(tile)
+            for name in bf.case_names(60, "gw"):
+                case = bf.make_geometry_case(name, max_channels=8)
+                got = engine.decode_host([case["image"]])[0]
+                want = bf.oracle_decode(case["image"])
+                assert np.array_equal(got, want), (mapping, tile, name, case["channels"], case["bits"], case["block_size"], case["spb"], case["fits"],
+                                                   case["blocks"], _first_diff(got, want))
+    finally:
+        engine.set_mapping("auto")
+        engine.set_tile_kbytes(0)
 
 
 def test_header_index_field_beyond_the_table(engine):
