@@ -12,6 +12,14 @@ bool decode_tiled_applicable(const DecodeArgs &a)
   if (a.channels < 1 || a.channels > 2) return false;
   if (a.bits < 2 || a.bits > 4) return false;
   if (!a.pcm_aligned16) return false;
+  {
+    /* A block whose header asks for more samples than its block_size holds reads on into the bytes behind it (the reference's
+     * code walk has no bound, src/aad_decoder.c:396-451; no encoder writes such a header).  The rows' rings are laid out for
+     * blocks that keep to themselves: those streams take the per-lane kernel, which reads through to the end of the stream. */
+    const uint64_t us = a.bits == 3 ? 8u : (a.bits == 4 ? 2u : 4u), ub = (uint64_t)(a.bits == 3 ? 3u : 1u) * a.channels;
+    const uint64_t coded = a.samples_per_block > 4 ? a.samples_per_block - 4 : 0;
+    if ((uint64_t)kBlockHeaderBytesPerCh * a.channels + (coded + us - 1) / us * ub > a.block_size) return false;
+  }
   /* every block of a stream starts on a piece boundary: the block length in PCM bytes is a multiple of 16 (mono 2-bit
    * blocks of 1024 bytes hold 4028 samples = 8056 bytes: 8 mod 16, which the kernel takes with a short lead chunk) - or no stream has a second block */
   const uint64_t block_pcm_bytes = (uint64_t)a.samples_per_block * a.channels * 2u;

@@ -1568,7 +1568,12 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
   if (!guard.ok || !ensure_events(ctx)) return AAD_APIRESULT_NG;
   if (decoded_frames) memset(decoded_frames, 0, sizeof(uint32_t) * num_streams);
 
-  TilePlanner planner(blocks.data(), num_streams, (uint64_t)spb * ch * sizeof(int16_t) + bs, tile_budget(ctx, total));
+  /* bytes a full block's decode touches beyond its own block_size (0 for every geometry an encoder writes) */
+  const uint64_t unit_samples = format->bits_per_sample == 3 ? 8 : (format->bits_per_sample == 4 ? 2 : 4);
+  const uint64_t unit_bytes = (uint64_t)(format->bits_per_sample == 3 ? 3 : 1) * ch;
+  const uint64_t touched = (uint64_t)AAD_BLOCK_HEADER_BYTES_PER_CH * ch + (spb > 4 ? (spb - 4 + unit_samples - 1) / unit_samples * unit_bytes : 0);
+  const uint64_t overreach = touched > bs ? touched - bs : 0;
+  TilePlanner planner(blocks.data(), num_streams, (uint64_t)spb * ch * sizeof(int16_t) + bs + overreach, tile_budget(ctx, total));
   const bool piped = batch_is_cut(ctx, total);
   if (piped && !ensure_pipeline(ctx)) return AAD_APIRESULT_NG;
   const Route route = route_for(ctx, piped);
@@ -1614,7 +1619,12 @@ AADApiResult decode_host(AADHipContext *ctx, const struct AADHeaderInfo *format,
     for (uint32_t k = 0; k < n; k++) {
       const uint32_t i = order[k];
       const uint64_t payload = data_size[i] - head; /* alive: it has a block, so more than `head` bytes */
-      const uint64_t byte0 = step.block0 * bs, byte1 = step.block1 * bs < payload ? step.block1 * bs : payload;
+      /* a block whose header asks for more samples than block_size holds reads on into the bytes behind it, as the reference's
+       * unbounded code walk does (src/aad_decoder.c:396-451; the header checks relate samples_per_block and block_size to
+       * nothing, :173-225): a tile carries that reach behind its last block, and a stream's last tile every byte that is left */
+      const uint64_t byte0 = step.block0 * bs;
+      const uint64_t upto = step.block1 >= blocks[i] ? payload : step.block1 * bs + overreach;
+      const uint64_t byte1 = upto < payload ? upto : payload;
       const uint64_t frame0 = step.block0 * spb, frame1 = step.block1 * spb < num_samples[i] ? step.block1 * spb : num_samples[i];
       /* frames the reference's block walk produces: it stops when the bytes run out (src/aad_decoder.c:514) */
       tile_blocks[k] = (step.block1 < blocks[i] ? step.block1 : blocks[i]) - step.block0;
