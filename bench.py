@@ -831,14 +831,23 @@ def main():
                           "note": "one context, the decode of step k ends before the encode of step k+1 starts"}
 
     extras = world == 1 and rank == 0 and not args.no_extras
-    if extras and not args.serial:
-        line["in_flight"] = measure_in_flight(torch, Engine, local, pcm, param, max(20, args.steps), min(args.warmup, 10), n_step)
-    if extras:
+
+    def guarded(key, leg):
+        """An auxiliary leg must not take the headline down: whatever it raises goes on the line under its key, and the run goes on
+        (the headline above has been measured; a leg that failed inside a collective of an N > 1 run fails on every rank alike)."""
+        try:
+            v = leg()
+            if v is not None:
+                line[key] = v
+        except Exception as e:  # noqa: BLE001 - reported, not raised
+            line[key] = {"error": repr(e)[:400]}
+
+    def trials2_leg():
         # the reference CLI's default operating point: the same batch with the trial search (src/main.c:45-47)
         p2 = make_parameter(ch, bits, mbs, 48000, False, 2)
         m2 = measure(engine, torch, dist, pcm, p2, max(10, args.steps // 4), 3, 1, 1, keep=True, decode_engine=decode_engine, repeats=5, max_repeats=5)
         e2 = n_step * bps / (m2["enc_ms"] * 1e-3) / 1e9
-        line["trials2"] = {
+        return {
             "workload": "the headline batch with num_encode_trials = 2 (reference CLI default, src/main.c:45-47)",
             "value": round(2.0 * n_step * max(10, args.steps // 4) / m2["wall_s"] / 1e6, 3), "unit": "Msamples/s",
             "ms_per_step": round(m2["wall_s"] / max(10, args.steps // 4) * 1e3, 5),
@@ -847,7 +856,8 @@ def main():
             "encode_frac": round(e2 / HBM_PEAK_GBS, 6),
             "bit_exact_vs_reference_golden": golden_check(m2, args.streams, samples, ch, bits, 2),
         }
-        line["end_to_end"] = end_to_end(engine, torch, pcm_np, param)
+
+    def configs_leg():
         cfgs = [
             ("cfg2(ii) 1000 stereo 4-bit streams x 16 blocks", 1000, 992 * 16, 2, 4, 0, 5, "corpus", "cfg2ii"),
             ("cfg2(iii) 1 stereo 4-bit stream x 1000 blocks (serial worst case: 2 encode recurrences)", 1, 992 * 1000, 2, 4, 0, 2, "corpus"),
@@ -856,16 +866,29 @@ def main():
             ("cfg4 10000 x 8-channel 2-bit one-block segments", 10000, 444, 8, 2, 0, 10, "eight", "cfg4_2bit"),
             ("cfg5 per-GPU shard: 1250 stereo 4-bit files x 10 blocks", 1250, 9920, 2, 4, 0, 5, "corpus", "cfg5_shard"),
         ]
-        line["configs"] = [config_entry(engine, torch, dist, *c) for c in cfgs]
+        rows = []
+        for c in cfgs:
+            try:
+                rows.append(config_entry(engine, torch, dist, *c))
+            except Exception as e:  # noqa: BLE001 - this row only
+                rows.append({"config": c[0], "error": repr(e)[:400]})
+        return rows
 
-    if not args.no_saturated and rank == 0:  # per-kernel figures of ONE GPU: rank 0 alone, no collective inside
+    if extras and not args.serial:
+        guarded("in_flight", lambda: measure_in_flight(torch, Engine, local, pcm, param, max(20, args.steps), min(args.warmup, 10), n_step))
+    if extras:
+        guarded("trials2", trials2_leg)
+        guarded("end_to_end", lambda: end_to_end(engine, torch, pcm_np, param))
+        guarded("configs", configs_leg)
+
+    def saturated_leg():  # per-kernel figures of ONE GPU: rank 0 alone, no collective inside
         big_streams = args.saturated_streams  # 262144 stereo streams = 8192 waves = 8 per SIMD (dense mapping)
         reps = -(-big_streams // args.streams)
         big = pcm.repeat((reps, 1, 1))[:big_streams].contiguous()
         ms = measure(engine, torch, dist, big, param, 5, 1, 1)
         del big
         nb = big_streams * samples * ch
-        line["saturated"] = {
+        sat = {
             "workload": "%d stereo streams x %d samples/ch per launch (the step batch tiled)" % (big_streams, samples),
             "encode_msps": round(nb / (ms["enc_ms"] * 1e-3) / 1e6, 1), "decode_msps": round(nb / (ms["dec_ms"] * 1e-3) / 1e6, 1),
             "encode_gbs": round(nb * bps / (ms["enc_ms"] * 1e-3) / 1e9, 2), "decode_gbs": round(nb * bps / (ms["dec_ms"] * 1e-3) / 1e9, 2),
@@ -875,7 +898,7 @@ def main():
         }
         for role, kms, per_rec in (("encode", ms["enc_ms"], samples), ("decode", ms["dec_ms"], hd.num_samples_per_block)):
             st, note = pmc_stamp("saturated", role, big_streams, samples)
-            line["saturated"][role] = dict({"kernel": (st or {}).get("kernel"), "kernel_ms": round(kms, 5)},
+            sat[role] = dict({"kernel": (st or {}).get("kernel"), "kernel_ms": round(kms, 5)},
                                            **traffic_fields(st, note, int(round(nb * bps))),
                                            **{"valu": valu_fields(st, note, kms, per_rec, role)})
 
@@ -898,12 +921,15 @@ def main():
                             "encode_frac": round(g_n * g_bps / (gm["enc_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                             "decode_frac": round(g_n * g_bps / (gm["dec_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
                 del g_pcm, tile
-            line["saturated"]["geometries"] = geo
+            sat["geometries"] = geo
+        return sat
+
+    if not args.no_saturated and rank == 0:
+        guarded("saturated", saturated_leg)
 
     if world > 1 and args.blocks == 1:
-        c5 = config5_batched_files(engine, torch, dist, rank, world)
-        if rank == 0:
-            line["config5"] = c5
+        # every rank takes part; a failure inside a collective is every rank's alike and goes on the line instead of ending the run
+        guarded("config5", lambda: config5_batched_files(engine, torch, dist, rank, world))
     elif world == 1 and args.blocks == 1 and not args.no_config5:
         # One GPU: the same leg under a ONE-rank RCCL process group with the collectives forced (a world of one would
         # skip them), so that the code an N > 1 run depends on - init_process_group(device_id=), broadcast and
@@ -930,21 +956,25 @@ def main():
         except Exception as e:  # noqa: BLE001 - reported, not raised
             line["config5"] = {"error": repr(e)[:400], "backend": "nccl", "world_size": 1}
 
-    if rank == 0 and not args.no_cpu_baseline:  # N > 1 too: the host cores are the same box's; the other ranks wait at the barrier below
+    def cpu_leg():
         trials_list = [args.trials] + ([2] if extras and args.trials != 2 else [])
         cpu = cpu_baseline(pcm_np, bits, mbs, trials_list)
-        line["cpu_baseline"] = cpu[args.trials]
-        line["cpu_baseline"]["gpu_over_cpu"] = round(value / cpu[args.trials]["value"], 1)
+        out = cpu[args.trials]
+        out["gpu_over_cpu"] = round(value / cpu[args.trials]["value"], 1)
         if world > 1:
-            line["cpu_baseline"]["gpu_over_cpu_note"] = "whole job (%d GPUs) over ONE host core" % world
-        if "trials2" in line and 2 in cpu:
+            out["gpu_over_cpu_note"] = "whole job (%d GPUs) over ONE host core" % world
+        if isinstance(line.get("trials2"), dict) and "value" in line["trials2"] and 2 in cpu:
             line["trials2"]["cpu_baseline"] = cpu[2]
             line["trials2"]["gpu_over_cpu"] = round(line["trials2"]["value"] / cpu[2]["value"], 1)
-        if "end_to_end" in line:
+        if isinstance(line.get("end_to_end"), dict) and "host_memory_api" in line["end_to_end"]:
             line["end_to_end"]["host_memory_api"]["encode_over_cpu_single_thread"] = round(
                 line["end_to_end"]["host_memory_api"]["encode_msps"] / cpu[args.trials]["encode_msps"], 1)
             line["end_to_end"]["host_memory_api"]["decode_over_cpu_single_thread"] = round(
                 line["end_to_end"]["host_memory_api"]["decode_msps"] / cpu[args.trials]["decode_msps"], 1)
+        return out
+
+    if rank == 0 and not args.no_cpu_baseline:  # N > 1 too: the host cores are the same box's; the other ranks wait at the barrier below
+        guarded("cpu_baseline", cpu_leg)
     engine.close()
     if rank == 0:
         sys.stdout.flush()
