@@ -605,13 +605,13 @@ def test_extreme_block_sizes(engine, mapping):
             assert np.array_equal(dec[s], ob.decode(images[s])[0]), (ch, bits, mbs)
 
 
-@pytest.mark.parametrize("streams,bits,ch", [(3000, 4, 2), (7000, 4, 1), (4608, 4, 2), (4609, 4, 2), (8192, 4, 2), (8193, 4, 2),
-                                             (4096, 3, 2), (4097, 3, 2), (9000, 3, 2), (6144, 2, 2), (6145, 2, 2), (12288, 2, 1),
-                                             (12289, 4, 1), (17000, 3, 1)])
+@pytest.mark.parametrize("streams,bits,ch", [(3000, 4, 2), (7000, 4, 1), (4096, 4, 2), (4097, 4, 2), (8192, 4, 2), (8193, 4, 2),
+                                             (2048, 3, 2), (2049, 3, 2), (4096, 3, 2), (4097, 3, 2), (9000, 3, 2), (4096, 2, 2), (4097, 2, 2),
+                                             (4096, 2, 1), (8192, 2, 1), (8193, 4, 1), (12289, 4, 1), (16384, 3, 1), (17000, 3, 1)])
 def test_decode_mapping_ranges_auto(engine, streams, bits, ch):
     """The host's own choice of mapping on both sides of every threshold of its per-geometry table
     (mapping option "auto"; aad_hip_engine.hip mapping_limits: encode quad up to 16384 recurrences,
-    decode split up to 12288 - 9216 for 4-bit stereo, 8192 for 3-bit stereo -, dense beyond): split
+    decode split up to 8192 recurrences - 4096 of them with the residual rows in LDS -, dense beyond): split
     decoder with the residuals in LDS / in a device scratch buffer, dense kernel -
     one-block streams, sampled against the oracle, and the whole batch through the round trip
     decode(encode(x)) == oracle decode."""
