@@ -564,8 +564,18 @@ template <bool BITMASK = true>
 __device__ __forceinline__ QuadLane to_quad(const Lane &L, uint32_t tap)
 {
   QuadLane Q;
-  Q.w = tap == 0 ? L.w0 : (tap == 1 ? L.w1 : (tap == 2 ? L.w2 : L.w3));
-  Q.h = tap == 0 ? L.h0 : (tap == 1 ? L.h1 : (tap == 2 ? L.h2 : L.h3));
+  /* tap t's weight and history by bit masks, the masks opaque to the compiler: written as a chain of conditionals
+   * (tap == 0 ? L.w0 : tap == 1 ? L.w1 : ...) LLVM turned the selection into a table on the STACK - nine scratch stores and two
+   * indexed scratch loads per block boundary, and a kernel that uses scratch at all is launched under the queue's scratch-wave
+   * limit: the dual trial-search encoder (76 bytes of scratch per lane) ran at most ~540 waves at a time, so batches of
+   * 4097-8192 recurrences took up to 1.6x as long as their waves needed (profiles/r04_trial_search_size_sweep.txt). */
+  uint32_t m0 = tap == 0 ? 0xFFFFFFFFu : 0u, m1 = tap == 1 ? 0xFFFFFFFFu : 0u, m2 = tap == 2 ? 0xFFFFFFFFu : 0u, m3 = tap == 3 ? 0xFFFFFFFFu : 0u;
+  pin(m0);
+  pin(m1);
+  pin(m2);
+  pin(m3);
+  Q.w = (int32_t)(((uint32_t)L.w0 & m0) | ((uint32_t)L.w1 & m1) | ((uint32_t)L.w2 & m2) | ((uint32_t)L.w3 & m3));
+  Q.h = (int32_t)(((uint32_t)L.h0 & m0) | ((uint32_t)L.h1 & m1) | ((uint32_t)L.h2 & m2) | ((uint32_t)L.h3 & m3));
   Q.idxb = L.idxb;
   Q.round = tap == 0 ? 16384u : 0u;
   Q.tap0 = tap == 0;

@@ -330,10 +330,16 @@ unsigned dense_encode_lds_pad(uint32_t bits, uint64_t lanes, unsigned static_lds
 /* On the quad mapping the trial search's probe strand gets lanes of its own ("dual"): one pass of
  * latency less per block with a predecessor, nothing lost otherwise (tools/trial_probe.py).
  * AAD_HIP_OPTION_TRIAL_LANES = single keeps both strands on the same lanes (the parity tests run both). */
+/* Round 4: ... up to kDualMaxRecurrences.  The dual layout spends eight lanes per recurrence; from ~640 waves on (5120 recurrences)
+ * its launch slows down faster than the work grows and the one-after-the-other layout - flat up to 16 384 recurrences - overtakes it
+ * in every geometry (stereo 4-bit, t = 2: dual 0.146 / 0.161 / 0.231 ms at 4096 / 5120 / 6144 recurrences, single 0.188-0.190;
+ * profiles/r04_trial_search_size_sweep.txt). */
+constexpr uint64_t kDualMaxRecurrences = 5120;
 bool pick_dual(const AADHipContext *ctx, const aad::EncodeArgs &a, bool quad)
 {
   if (!quad || a.trials == 0) return false;
   if (a.trial_scratch == nullptr) return false; /* run_encode could not provide the slots */
+  if ((uint64_t)a.num_streams * a.channels > kDualMaxRecurrences) return false;
   return ctx->trial_lanes != AAD_HIP_TRIAL_LANES_SINGLE;
 }
 
@@ -353,8 +359,12 @@ void launch_encode(const AADHipContext *ctx, const aad::EncodeArgs &a)
   /* dual: eight lanes per recurrence put a wave on twice as many CUs as the trial-free launch; two waves
    * per workgroup (two SIMDs of one CU) keep a small batch on half the chip, so that a decode launched
    * beside it finds free CUs (bench.py's pipelined step with trials 2: 158 -> see DESIGN.md) */
-  unsigned wg = dual && threads <= 64ull * 1024ull ? 128u : pick_workgroup(threads);
-  if (!quad && !a.trials)
+  /* (round 4: two-wave workgroups only while there is at most one of them per CU - 256 workgroups, 4096 recurrences.  Beyond that a
+   * CU receives a second workgroup whose two waves land on the SIMDs the first one's already use, the other two SIMDs stay empty
+   * and the launch takes 1.6x as long: stereo 4-bit, t = 2, 6000 recurrences 0.229 ms against 0.143 at 4096;
+   * profiles/r04_trial_search_size_sweep.txt.  One-wave workgroups spread over the SIMDs.) */
+  unsigned wg = dual && threads <= 32ull * 1024ull ? 128u : pick_workgroup(threads);
+  if (!quad) /* the dense encoders, with and without the trial search: one-wave workgroups only while their LDS lets all of them be resident */
     wg = dense_encode_workgroup(lanes, a.channels == 1 ? (unsigned)aad::kLdsBytesEncoder<BITS, 1, false>
                                        : (a.channels == 2 ? (unsigned)aad::kLdsBytesEncoder<BITS, 2, false> : (unsigned)aad::kLdsBytesEncoder<BITS, 0, false>));
   const dim3 grid((unsigned)((threads + wg - 1) / wg)), block(wg);
@@ -660,6 +670,7 @@ AADApiResult run_encode(AADHipContext *ctx, const aad::EncodeArgs &args)
   a.trial_slot_bytes = 0;
   if ((reinterpret_cast<uintptr_t>(a.data) & 63u) != 0) a.ring_ok = 0;
   if (a.trials != 0 && a.channels <= 2 && ctx->trial_lanes != AAD_HIP_TRIAL_LANES_SINGLE &&
+      (uint64_t)a.num_streams * a.channels <= kDualMaxRecurrences &&
       pick_quad(ctx, (uint64_t)a.num_streams * a.channels, a.channels, a.bits)) {
     const uint64_t want = (uint64_t)a.num_streams * 3u * trial_slot_bytes(a);
     if (want <= kMaxTrialScratchBytes) { /* else: the search and the encode one after the other on the same lanes */

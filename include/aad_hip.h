@@ -119,7 +119,8 @@ enum AADHipLaneMapping {
   AAD_HIP_LANE_MAPPING_DENSE_TILED = 4 /* one lane per recurrence, memory moved in whole sectors / lines through LDS where the layout allows (else: dense) */
 };
 enum AADHipTrialLanes {
-  AAD_HIP_TRIAL_LANES_DUAL = 0,  /* trial search on the quad mapping: a second group of lanes runs the probe and encodes every candidate beside the chain */
+  AAD_HIP_TRIAL_LANES_DUAL = 0,  /* trial search on the quad mapping: a second group of lanes runs the probe and encodes every candidate beside the chain
+                                  * (batches of up to 5120 recurrences, where it pays; larger ones take the other layout) */
   AAD_HIP_TRIAL_LANES_SINGLE = 1 /* both strands on the same lanes */
 };
 AADApiResult AADHip_ContextSetOption(struct AADHipContext *context, int32_t option, int32_t value);
