@@ -466,7 +466,10 @@ enum class DecodeMapping { Dense, QuadFused, QuadSplit };
  * tiled one at any size. */
 uint64_t tiled_decode_min(uint32_t bits, uint32_t channels)
 {
-  if (channels == 1) return 65536u;
+  /* round 4 (tools/size_sweep.py --mapping dense | dense-tiled): at exactly 65 536 mono lanes the per-lane kernel still runs one
+   * wave per SIMD in one-wave workgroups and is 7 % ahead (0.154 vs 0.165 ms); from the next lane on it needs a second wave per
+   * SIMD and the tiled kernel is level (80 000) to 18 % ahead (524 288) */
+  if (channels == 1) return 65537u;
   return bits == 4 ? 393216u : ~0ull;
 }
 

@@ -31,7 +31,10 @@ def main():
     if args.geometries:
         geometries = tuple(tuple(int(v) for v in g.split("x")) for g in args.geometries.split(","))
     for ch, bits in geometries:
-        spb = {4: 1984, 3: 2632, 2: 3960}[bits] // ch
+        import ctypes as C
+        bs_, spb_ = C.c_uint16(0), C.c_uint32(0)
+        assert engine.lib.AADEncoder_CalculateBlockSize(1024, ch, bits, C.byref(bs_), C.byref(spb_)) == 0 or ch > 2
+        spb = spb_.value if ch <= 2 else {4: 224, 3: 292, 2: 444}[bits] * 8 // ch if ch == 8 else {4: 1984, 3: 2632, 2: 3960}[bits] // ch // 8 * 8
         base = torch.from_numpy(synth_pcm(1000, spb, ch, seed=1234)).cuda()
         param = make_parameter(ch, bits, 1024, 48000, False, args.trials)
         for lanes in sizes:
