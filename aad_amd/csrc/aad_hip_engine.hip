@@ -1090,7 +1090,10 @@ unsigned staging_threads(const AADHipContext *ctx)
 {
   if (ctx->staging_threads > 0) return (unsigned)ctx->staging_threads;
   static const unsigned hw = std::thread::hardware_concurrency(); /* asked once: it reads /sys */
-  return hw >= 8 ? 4u : (hw >= 4 ? 2u : 1u);
+  /* round 4 (tools/host_size_sweep.py, 100 000 one-block stereo streams = 0.5 GB per direction): decode 7.9 / 10.9 / 12.0 / 13.6
+   * Gsamples/s with 2 / 4 / 6 / 8 copying threads - the drain of 2 bytes per sample into pageable memory is the slowest stage -
+   * so a host with cores to spare takes eight */
+  return hw >= 32 ? 8u : (hw >= 8 ? 4u : (hw >= 4 ? 2u : 1u));
 }
 
 void staging_pool_main(StagingPool *p, unsigned index)

@@ -96,7 +96,7 @@ enum AADHipOption {
   AAD_HIP_OPTION_TRIAL_LANES = 1,  /* enum AADHipTrialLanes */
   /* Threads that copy between the caller's buffers and the pinned staging blocks in the host-memory
    * entry points (...Batch, EncodeWhole/DecodeWhole), the caller's own included: 0 = by core count
-   * (4 from eight cores, 2 from four), 1 = the caller alone (no helper thread is ever started),
+   * (8 from thirty-two cores, 4 from eight, 2 from four), 1 = the caller alone (no helper thread is ever started),
    * up to 8.  Helpers start at the first chunk of a megabyte or more and end in ContextDestroy. */
   AAD_HIP_OPTION_STAGING_THREADS = 2,
   /* Budget, in KiB, of one tile of the host-memory entry points (input + output bytes that travel
