@@ -75,3 +75,35 @@ def test_batches_with_high_counts_and_tiles(engine, trials, trial_lanes):
     finally:
         engine.set_mapping("auto", trial_lanes="dual")
         engine.set_tile_kbytes(0)
+
+
+@pytest.mark.parametrize("streams,ch,bits,trials,ms", [
+    (2048, 2, 4, 2, False),   # 4096 recurrences: dual layout, two-wave workgroups, one per CU
+    (2100, 2, 4, 2, False),   # 4200: dual layout, one-wave workgroups
+    (2560, 2, 3, 1, True),    # 5120: the last batch of the dual layout
+    (2561, 2, 4, 2, False),   # 5122: the one-after-the-other layout on the quad mapping
+    (9000, 1, 2, 1, False),   # 9000 mono recurrences, quad mapping, search then encode
+    (8200, 2, 4, 3, False),   # 16 400: the dense trial-search encoder, one-wave workgroups
+    (57000, 1, 4, 1, False),  # 57 000 mono lanes: the dense trial-search encoder in four-wave workgroups (its LDS fits three one-wave ones per CU)
+    (33000, 2, 3, 1, False),  # 66 000 lanes: beyond one wave per SIMD
+])
+def test_trial_search_launch_ranges(engine, streams, ch, bits, trials, ms):
+    """Both sides of every launch-geometry switch of the trial search (aad_hip_engine.hip: pick_dual / kDualMaxRecurrences, the dual
+    kernel's workgroup size, mapping_limits.encode_quad, dense_encode_workgroup) under the default options: device-resident
+    one-block batches, sampled streams against the oracle, and every copy of a base stream identical."""
+    import torch
+    engine.set_mapping("auto", trial_lanes="dual")
+    spb = ob.geometry(1024, ch, bits)[2]
+    base = synth_pcm(250, spb, ch, seed=31 * streams + bits)
+    pcm = np.concatenate([base] * (-(-streams // 250)))[:streams]
+    param = make_parameter(ch, bits, 1024, 48000, ms, trials)
+    d_img, size = engine.encode_uniform(torch.from_numpy(np.ascontiguousarray(pcm)).cuda(), param)
+    torch.cuda.synchronize()
+    img = d_img.cpu().numpy()
+    for s in list(range(0, 250, 23)) + [249]:
+        want = ob.encode(base[s], bits, 1024, 48000, ms, trials)
+        for copy in range(s, streams, 250 * max(1, streams // 250 // 3)):
+            assert bytes(img[copy, :size]) == want, (streams, ch, bits, trials, s, copy)
+    assert np.array_equal(img[:250], img[250:500])
+    tail = streams - streams % 250 - 250
+    assert np.array_equal(img[tail:tail + 250], img[:250])
