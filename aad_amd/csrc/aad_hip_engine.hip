@@ -230,8 +230,9 @@ MappingLimits mapping_limits(uint32_t bits, uint32_t channels)
    * (59-60 us on one-block stereo 4-bit streams, 250 to 48 000 recurrences; fused 61-67 us up to 16 384):
    * "auto" no longer picks the fused kernel (its range is empty), the option still forces it. */
   /* Round 4 (tools/size_sweep.py --mapping quad | dense, profiles/r04_decode_split_crossover.txt): the split decoder runs
-   * 1024-thread workgroups of 16 recurrences, two to a CU, so 8192 recurrences are its last single round of workgroups - up to
-   * there it beats the dense kernel in every geometry (mono 4-bit 0.090 vs 0.116 ms at 8192), from 9000 on it loses in every
+   * 1024-thread workgroups of 16 recurrences, ONE to a CU (84-94 VGPRs x 16 waves), i.e. rounds of 4096 recurrences: its time is
+   * about 0.025 + 0.015 ms x rounds on stereo 4-bit.  Up to two rounds (8192 recurrences) it beats the dense kernel in every
+   * geometry (mono 4-bit 0.090 vs 0.116 ms at 8192), from the third round on (9000) it loses in every
    * geometry (0.120 vs 0.116) and its residual scratch (recurrences x block x 4 bytes, ~100 MB at 12 288 mono rows) pushes the
    * NEXT launch's input out of the caches: a mono 4-bit encode behind it took 0.15-0.20 ms instead of 0.127.  Round 2's
    * per-geometry limits (12 288; 9 216 / 8 192 for 4- / 3-bit stereo) predate the dense decoder's round-3 speed-ups. */
