@@ -219,7 +219,11 @@ AADApiResult AADHip_ReconstructPlanRun(
     int16_t *device_out, int32_t output_kind, struct AADHipErrorStats *device_stats);
 
 /* host-memory form.  out_pcm: NULL (statistics only - nothing but 24 bytes per stream comes
- * back over PCIe) or per-stream buffers of num_samples[i] frames; stats: NULL or num_streams. */
+ * back over PCIe) or per-stream buffers of num_samples[i] frames; stats: NULL or num_streams.
+ * Any batch size: the compute runs over a WAVE of whole streams resident on the device (one ReconstructPlanRun: the encoders'
+ * block chains side by side, the statistics summed per stream as the plan form does), the PCM goes up and the output comes down
+ * through the context's pinned blocks in chunks of the tile budget (AAD_HIP_OPTION_TILE_KBYTES), and a batch beyond three
+ * quarters of the device's free memory is run as several waves of consecutive streams.  Results do not depend on any of it. */
 AADApiResult AADHip_ReconstructBatch(
     struct AADHipContext *context, const struct AADEncodeParameter *parameter,
     uint32_t num_streams, const int16_t *const *pcm, const uint32_t *num_samples,
