@@ -13,12 +13,18 @@ Headline workload (BASELINE.json configs[1]+[2], SURVEY.md section 8d "Config 2/
   corpus (aad_amd/synth.py, seed 1234) -> encode to .aad images, then decode those images.
   A "step" = one encode pass + one decode pass over the batch, inputs resident in HBM.
   1 sample = 1 channel-sample; value = (samples encoded + samples decoded) / time, whole job.
+  Round 4: TWO steps in flight (`--in-flight 2`, the default): a 1000-stream step puts 125 waves per kernel on a chip of 1024 SIMDs,
+  so step k runs on pipeline k mod 2 - two encode and two decode contexts on four streams, one hardware queue each; every step still
+  encodes the whole batch and decodes what it encoded.  `one_pipeline` (= `--in-flight 1`, rounds 2-3's headline) and `serial` stay
+  on the line.
 Multi-GPU: streams are independent, so every rank runs its own batch (different corpus streams),
 no data-path collective: "scaling": "weak".
 
 Extra objects on the JSON line (N = 1 unless stated):
   roofline      the dominant kernel (encode_streams_kernel) against the HBM roof, from HIP events
                 carried by the kernels' own dispatch packets (AADHip_ContextSignalNextRun) inside the timed region
+  one_pipeline  rounds 2-3's headline: ONE step pipeline (the encode of step k+1 beside the decode of step k), same K
+  serial        the step with nothing overlapped
   trials2       the same batch with num_encode_trials = 2, the reference CLI's default (src/main.c:45-47)
   end_to_end    PCIe-inclusive figures for the same batch: pinned buffers + device plans, and the
                 host-memory C-ABI (AADHip_EncodeBatch / AADHip_DecodeBatch, pageable caller buffers)
@@ -150,72 +156,38 @@ def valu_fields(stamp, note, kernel_ms, samples_per_recurrence, role):
     return v
 
 
-def measure_in_flight(torch, Engine, device, pcm, param, steps, warmup, n_step, depths=(2, 4)):
-    """NOT the headline: the same steps with several of them in flight.  The headline pipeline keeps one encode and one decode
-    running (two contexts); a 1000-stream step leaves most of the chip idle, so `depth` such pipelines, stepped in turn
-    (step k on pipeline k mod depth, each with its contexts, image ring and output of its own), show what a caller with
-    independent batches to hand gets.  Every step still encodes the whole batch and decodes what it encoded; all outputs
-    are compared."""
-    from aad_amd.engine import EncodeDecodePipeline
-    streams, samples, ch = pcm.shape
-    rows = []
-    for depth in depths:
-        engines = [(Engine(device, stream=torch.cuda.Stream(device)), Engine(device, stream=torch.cuda.Stream(device))) for _ in range(depth)]
-        pipes = [EncodeDecodePipeline(e, d, param, streams, samples, ring=16) for e, d in engines]
-        outs = [torch.zeros_like(pcm) for _ in range(depth)]
-        for k in range(warmup * depth):
-            pipes[k % depth].step(pcm, outs[k % depth])
-        regions = []
-        for _ in range(5):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                pipes[k % depth].step(pcm, outs[k % depth])
-            torch.cuda.synchronize()
-            regions.append(time.perf_counter() - t0)
-        dt = sorted(regions)[len(regions) // 2]
-        same = all(bool(torch.equal(o, outs[0])) for o in outs[1:])
-        rows.append({"steps_in_flight": depth, "contexts": 2 * depth, "value": round(2.0 * n_step * steps / dt / 1e6, 3),
-                     "ms_per_step": round(dt / steps * 1e3, 5), "outputs_identical": same})
-        for p_ in pipes:
-            p_.close()
-        for e, d in engines:
-            e.close()
-            d.close()
-    return {"workload": "the headline batch, several steps in flight (one encode + decode pipeline per step in flight, stepped in turn)",
-            "unit": "Msamples/s", "steps": steps, "depths": rows,
-            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (the HIP runtime's default)"),
-            "note": "not the headline: `value` above keeps ONE encode and one decode running; this shows the throughput of the same "
-                    "steps when the caller has independent batches to overlap (the chip is mostly idle on a 1000-stream step).  "
-                    "Streams beyond the runtime's hardware queues share one and serialise: two steps in flight (4 streams + the null "
-                    "stream) give 60 900 Msamples/s on the default 4 queues and 98 500 with GPU_MAX_HW_QUEUES=8; beyond that the "
-                    "single Python thread that launches everything is the limit"}
-
-
 def algorithmic_bytes_per_sample(channels, block_size, spb):
     """2 (int16 PCM) + block_size / (samples_per_block * channels)"""
     return 2.0 + block_size / float(spb * channels)
 
 
 def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1, keep=False, decode_engine=None,
-            repeats=1, min_timed_s=0.0, max_repeats=1, collective=False):
+            repeats=1, min_timed_s=0.0, max_repeats=1, collective=False, more_pipelines=()):
     """-> dict with wall ms/step (max over ranks) and mean kernel durations from HIP events.
 
     decode_engine: a second context (its own stream) -> the step is PIPELINED: the encode of step k+1
     runs while step k decodes - each of the two kernels fills half the chip's CUs on this batch - on two
     streams ordered by events, the images double-buffered so that an encode never overwrites what a
-    decode still reads.  Every step still encodes the whole batch and decodes exactly what it encoded."""
+    decode still reads.  Every step still encodes the whole batch and decodes exactly what it encoded.
+    more_pipelines: further (encode engine, decode engine) pairs -> SEVERAL STEPS IN FLIGHT: step k runs on pipeline
+    k mod (1 + len(more_pipelines)), each pipeline with its own contexts, streams, image ring and output buffer, so that
+    consecutive steps overlap in full (two encodes and two decodes at work at any time with one more pipeline)."""
     from aad_amd.engine import EncodeDecodePipeline, parse_header
     streams, samples, ch = pcm.shape
     out = torch.zeros((streams, samples, ch), dtype=torch.int16, device=pcm.device)
     pipe = enc = dec = None
+    pipes, outs = [], [out]
     if decode_engine:
         pipe = EncodeDecodePipeline(engine, decode_engine, param, streams, samples, ring=32)  # one cross-stream wait per 16 encodes
+        pipes = [pipe] + [EncodeDecodePipeline(e_, d_, param, streams, samples, ring=32) for e_, d_ in more_pipelines]
+        outs = [out] + [torch.zeros_like(out) for _ in more_pipelines]
         header, image_size = pipe.header, pipe.enc.image_size
-        last = [None]
+        last, turn = [None], [0]
 
         def step(events=None):
-            last[0] = pipe.step(pcm, out, events)
+            p_ = turn[0] % len(pipes)
+            turn[0] += 1
+            last[0] = pipes[p_].step(pcm, outs[p_], events)
     else:
         enc = engine.uniform_encode_plan(param, streams, samples)
         img = torch.zeros((streams, enc.stride), dtype=torch.uint8, device=pcm.device)
@@ -277,11 +249,16 @@ def measure(engine, torch, dist, pcm, param, steps, warmup, world, event_every=1
     ok = bool((out == pcm).float().mean() > 0.0)  # touch the result so nothing is elided
     res = dict(wall_s=dt, wall_min_s=ordered[0], wall_max_s=ordered[-1], regions=len(regions), timed_s=sum(regions),
                enc_ms=enc_ms, dec_ms=dec_ms, header=header, touched=ok, image_size=image_size)
+    if pipes:
+        out = outs[(turn[0] - 1) % len(pipes)]  # the LAST step's output
+        res["outputs_identical"] = all(bool(torch.equal(o, outs[0])) for o in outs[1:])  # every pipeline decoded the same batch
+        res["steps_in_flight"] = len(pipes)
     if keep:  # what the LAST timed step left in HBM, for the bit-exact flags
         res["img"] = last[0][:, :image_size].contiguous().cpu().numpy()
         res["out"] = out.cpu().numpy()
-    if pipe:
-        pipe.close()
+    if pipes:
+        for p_ in pipes:
+            p_.close()
     else:
         enc.close()
         dec.close()
@@ -684,6 +661,8 @@ def main():
     ap.add_argument("--saturated-streams", type=int, default=262144)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--serial", action="store_true", help="do not overlap the encode of step k+1 with the decode of step k")
+    ap.add_argument("--in-flight", type=int, default=2, choices=(1, 2),
+                    help="steps in flight: 2 (default) = two encode + decode pipelines on four streams, stepped in turn; 1 = one pipeline (rounds 2-3)")
     ap.add_argument("--event-every", type=int, default=8, help="bracket the kernels with HIP events on every n-th timed step")
     ap.add_argument("--repeats", type=int, default=9, help="time the K-step region at least this many times; the line reports the median region")
     ap.add_argument("--min-timed-ms", type=float, default=50.0, help="...and until this much timed work has accumulated (at most 101 regions)")
@@ -728,7 +707,21 @@ def main():
 
     ch, bits, mbs = 2, 4, 1024
     param = make_parameter(ch, bits, mbs, 48000, False, args.trials)
+    # ALL the streams this run steps its pipelines on are made here, before the first host-to-device copy: the HIP runtime has four
+    # hardware queues and binds a stream to one when the stream is made (a later stream gets whichever queue is least used), and a
+    # pageable copy in between takes a queue for the runtime's own use - with the order engine, copy, other engines two of the four
+    # pipeline streams ended up on ONE queue and two steps in flight measured 60 000 instead of 87 000-101 000 Msamples/s, every time
+    # (tools/experiments/inflight_fresh.py ORDER=bench).  Each of the two kernels fills about half of the chip's CUs on this batch
+    # (125 workgroups), so the step is pipelined over two contexts: encode of step k+1 while step k decodes (see measure()).
+    # --serial runs the two launches of a step strictly one after the other, as rounds 1 and 2a did; the line carries that figure
+    # too (`serial`).
     engine = Engine(local)
+    decode_engine = None if args.serial else Engine(local, stream=torch.cuda.Stream(local))  # a stream of its own, not torch's current one
+    # the second pipeline (--in-flight 2): two more contexts on two more streams - four streams = the runtime's four hardware queues
+    second_pair = None
+    if not args.serial and args.in_flight == 2:
+        second_pair = (Engine(local, stream=torch.cuda.Stream(local)), Engine(local, stream=torch.cuda.Stream(local)))
+    more = (second_pair,) if second_pair else ()
     spb = 992
     samples = spb * args.blocks
     pcm_np = synth_pcm(args.streams, samples, ch, seed=1234, first_stream=rank * args.streams)
@@ -737,13 +730,9 @@ def main():
     torch.cuda.synchronize()
     # everything timed below is launched on the engine's stream, and the HIP events are recorded on it
     torch.cuda.set_stream(engine.stream)
-    # Each of the two kernels fills about half of the chip's CUs on this batch (125 workgroups), so the step
-    # is pipelined over two contexts: encode of step k+1 while step k decodes (see measure()).  --serial
-    # runs the two launches of a step strictly one after the other, as rounds 1 and 2a did; the line
-    # carries that figure too (`serial`).
-    decode_engine = None if args.serial else Engine(local, stream=torch.cuda.Stream(local))  # a stream of its own, not torch's current one
     m = measure(engine, torch, dist, pcm, param, args.steps, args.warmup, world, args.event_every, keep=(rank == 0),
-                decode_engine=decode_engine, repeats=args.repeats, min_timed_s=args.min_timed_ms * 1e-3, max_repeats=max(args.repeats, 101))
+                decode_engine=decode_engine, repeats=args.repeats, min_timed_s=args.min_timed_ms * 1e-3, max_repeats=max(args.repeats, 101),
+                more_pipelines=more)
     hd = m["header"]
     n_step = args.streams * samples * ch  # channel-samples per direction per rank
     value = 2.0 * n_step * world * args.steps / m["wall_s"] / 1e6  # the MEDIAN K-step region
@@ -784,10 +773,18 @@ def main():
             "lanes_encode": args.streams * ch,
             "lanes_decode": args.streams * args.blocks * ch,
             "value_counts": "samples encoded + samples decoded",
+            "steps_in_flight": m.get("steps_in_flight", 1),
             "pipeline": ("serial: the decode of step k ends before the encode of step k+1 starts" if args.serial else
-                         "two contexts on two streams: the encode of step k+1 overlaps the decode of step k (events order "
-                         "them, images double-buffered); every step encodes the whole batch and decodes what it encoded"),
+                         ("one pipeline - two contexts on two streams: the encode of step k+1 overlaps the decode of step k (events order "
+                          "them, images double-buffered); every step encodes the whole batch and decodes what it encoded") if not more else
+                         ("two steps in flight - two such pipelines (two encode and two decode contexts on four streams, one hardware queue "
+                          "each), step k on pipeline k mod 2: a 1000-stream step puts 125 waves per kernel on a chip of 1024 SIMDs, so two "
+                          "encodes and two decodes run side by side.  Every step encodes the whole batch and decodes exactly what it encoded, "
+                          "into a ring of image buffers and an output buffer of its pipeline's own; `ms_per_step` = region / K is therefore "
+                          "SHORTER than a step's own kernels (`roofline.kernel_ms`: a step takes as long as before, two of them share the "
+                          "time) - `one_pipeline` carries rounds 2-3's figure, `serial` the strictly sequential one")),
         },
+        "outputs_identical_across_pipelines": m.get("outputs_identical"),
         "bit_exact_vs_reference_golden": golden_check(m, args.streams, samples, ch, bits, args.trials) if rank == 0 else None,
         "encode_msps": round(n_step * world / (m["enc_ms"] * 1e-3) / 1e6, 3),
         "decode_msps": round(n_step * world / (m["dec_ms"] * 1e-3) / 1e6, 3),
@@ -801,7 +798,7 @@ def main():
                "kernel_ms": round(m["enc_ms"], 5),
                "kernel_ms_note": "HIP events carried by the encode kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop events via "
                                  "AADHip_ContextSignalNextRun: no packet around the kernel), on every %d-th step of the timed regions; "
-                                 "PIPELINED run: the decode of the previous step runs beside it (`serial.encode_kernel_ms` is the same "
+                                 "PIPELINED run: the other kernels in flight run beside it (`serial.encode_kernel_ms` is the same "
                                  "kernel with the chip to itself)" % args.event_every if not args.serial else
                                  "HIP events carried by the kernel's own dispatch packet, every %d-th step" % args.event_every,
                "valu": valu_fields(stamp_e, note_e, m["enc_ms"], samples, "encode"),
@@ -817,11 +814,18 @@ def main():
         # A short region (the driver passes K = 20) carries the pipeline's fill and drain - the first encode has no decode
         # beside it, the last decode runs behind the last encode: ~50 us per region.  The same pipeline over 200-step regions:
         ml = measure(engine, torch, dist, pcm, param, 200, min(args.warmup, 5), world, args.event_every, decode_engine=decode_engine,
-                     repeats=5, max_repeats=5)
+                     repeats=5, max_repeats=5, more_pipelines=more)
         line["steady_state"] = {"value": round(2.0 * n_step * 200 / ml["wall_s"] / 1e6, 3), "unit": "Msamples/s", "steps": 200,
                                 "ms_per_step": round(ml["wall_s"] / 200 * 1e3, 5),
                                 "note": "not the headline: the same pipelined step timed over regions of 200 steps (median of 5), where the "
-                                        "fill and drain of the two-stage pipeline (~50 us per region) weigh a tenth of what they do at K = %d" % args.steps}
+                                        "fill and drain of the pipeline (~60-100 us per region) weigh a tenth of what they do at K = %d" % args.steps}
+    if more:  # rounds 2-3's headline: ONE pipeline (the encode of step k+1 beside the decode of step k), same K
+        mo = measure(engine, torch, dist, pcm, param, args.steps, min(args.warmup, 5), world, args.event_every, decode_engine=decode_engine,
+                     repeats=5, max_repeats=5)
+        line["one_pipeline"] = {"value": round(2.0 * n_step * world * args.steps / mo["wall_s"] / 1e6, 3), "unit": "Msamples/s", "steps": args.steps,
+                                "ms_per_step": round(mo["wall_s"] / args.steps * 1e3, 5),
+                                "encode_kernel_ms": round(mo["enc_ms"], 5), "decode_kernel_ms": round(mo["dec_ms"], 5),
+                                "note": "one step pipeline (two contexts, two streams): what `value` was in rounds 2 and 3; `--in-flight 1` makes it the headline again"}
     if not args.serial:  # the same K steps with nothing overlapped, for reference
         ks = max(10, args.steps // 4)
         ms_ = measure(engine, torch, dist, pcm, param, ks, min(args.warmup, 3), world, args.event_every, repeats=5, max_repeats=5)
@@ -845,7 +849,8 @@ def main():
     def trials2_leg():
         # the reference CLI's default operating point: the same batch with the trial search (src/main.c:45-47)
         p2 = make_parameter(ch, bits, mbs, 48000, False, 2)
-        m2 = measure(engine, torch, dist, pcm, p2, max(10, args.steps // 4), 3, 1, 1, keep=True, decode_engine=decode_engine, repeats=5, max_repeats=5)
+        m2 = measure(engine, torch, dist, pcm, p2, max(10, args.steps // 4), 3, 1, 1, keep=True, decode_engine=decode_engine, repeats=5, max_repeats=5,
+                     more_pipelines=more)
         e2 = n_step * bps / (m2["enc_ms"] * 1e-3) / 1e9
         return {
             "workload": "the headline batch with num_encode_trials = 2 (reference CLI default, src/main.c:45-47)",
@@ -874,8 +879,6 @@ def main():
                 rows.append({"config": c[0], "error": repr(e)[:400]})
         return rows
 
-    if extras and not args.serial:
-        guarded("in_flight", lambda: measure_in_flight(torch, Engine, local, pcm, param, max(20, args.steps), min(args.warmup, 10), n_step))
     if extras:
         guarded("trials2", trials2_leg)
         guarded("end_to_end", lambda: end_to_end(engine, torch, pcm_np, param))
@@ -943,7 +946,7 @@ def main():
                 c5 = config5_batched_files(engine, torch, dist, 0, 1, force_collectives=True)
                 # the N > 1 timing path of measure() (barriers, MAX all_reduce on a device tensor), a short rehearsal
                 mr = measure(engine, torch, dist, pcm, param, 20, 3, 1, args.event_every, decode_engine=decode_engine,
-                             repeats=3, max_repeats=3, collective=True)
+                             repeats=3, max_repeats=3, collective=True, more_pipelines=more)
                 c5["collective_timing_rehearsal"] = {
                     "value": round(2.0 * n_step * 20 / mr["wall_s"] / 1e6, 3), "unit": "Msamples/s", "steps": 20, "regions": mr["regions"],
                     "note": "the headline step timed the way an N > 1 run times it: dist.barrier() on both sides of every region and "
@@ -975,6 +978,9 @@ def main():
 
     if rank == 0 and not args.no_cpu_baseline:  # N > 1 too: the host cores are the same box's; the other ranks wait at the barrier below
         guarded("cpu_baseline", cpu_leg)
+    if second_pair:
+        for e_ in second_pair:
+            e_.close()
     engine.close()
     if rank == 0:
         sys.stdout.flush()
