@@ -28,6 +28,9 @@ def test_bench_gpus_2_means_two_ranks():
     cpu = line["cpu_baseline"]
     assert cpu["cores"] == 1 and cpu["value"] > 0 and cpu["kind"] in ("reference", "port")
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    # two steps in flight on every rank, both pipelines' outputs identical, rounds 2-3's one-pipeline figure beside the headline
+    assert line["config"]["steps_in_flight"] == 2 and line["outputs_identical_across_pipelines"] is True
+    assert line["one_pipeline"]["value"] > 0 and line["serial"]["value"] > 0
 
 
 def test_bench_refuses_more_rccl_ranks_than_gpus():
